@@ -1,0 +1,159 @@
+"""The CPU oracle (oracle/bytenet_ref.py) against fixtures produced by the reference's own sources
+(oracle/make_golden.py).  No GPU, no /root/reference needed."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bytenet_ref as R
+
+TINY = dict(d_embed=8, d_model=64, n_layers=8, kernel_size=5, r=128, slim=True, activation="gelu")
+TINY_WIDE = dict(d_embed=8, d_model=256, n_layers=9, kernel_size=5, r=128, slim=False, activation="gelu")
+
+
+def sd_digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def arr_digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("tag,cfg,seed", [("tiny", TINY, 11), ("tinywide", TINY_WIDE, 12)])
+def test_forward_matches_reference(golden_dir, tag, cfg, seed):
+    g = load(golden_dir, f"{tag}_forward.npz")
+    m = R.build_model(cfg, None, seed)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert sd_digest(sd) == str(g["sd_sha"])
+    if tag == "tiny":
+        for k, v in sd.items():
+            assert np.array_equal(v.numpy(), g["sd/" + k]), k
+    for L in (7, 100, 300):
+        x = torch.from_numpy(g[f"x_L{L}"])
+        collect = []
+        with torch.no_grad():
+            y = m(x, torch.zeros(2, dtype=torch.long), collect=collect)
+        assert np.array_equal(y.numpy(), g[f"logits_L{L}"])          # same ops, same machine class
+        if g[f"blocks_L{L}"].size:
+            assert np.array_equal(torch.stack(collect).numpy(), g[f"blocks_L{L}"])
+
+
+def test_time_encoding_scramble(golden_dir):
+    g = load(golden_dir, "tiny_timeenc.npz")
+    m = R.build_model(TINY, 500, 13)
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])
+    assert np.array_equal(R.timestep_table(8, 500).numpy(), g["pe"])
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    with torch.no_grad():
+        assert np.array_equal(m.embedder.embed(x, y).numpy(), g["embed"])
+        assert np.array_equal(m(x, y).numpy(), g["logits"])
+    # the closed form of quirk Q1: row (b, l) gets pe[y[(b*L + l) % B]]
+    B, L = x.shape
+    idx = (torch.arange(B * L) % B).reshape(B, L)
+    pe = R.timestep_table(8, 500)[y][idx]
+    with torch.no_grad():
+        want = m.embedder.up_embedder(m.embedder.embedder(x) + pe)
+    assert torch.allclose(want, torch.from_numpy(g["embed"]), atol=1e-6)
+
+
+def test_38m_forward_and_param_count(golden_dir):
+    g = load(golden_dir, "m38_forward.npz")
+    m = R.build_model(R.MODEL_CONFIGS["38M"], None, 0)
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 37890327
+    assert len(m.state_dict()) == int(g["n_tensors"]) == 199
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]), torch.zeros(2, dtype=torch.long))
+    np.testing.assert_allclose(y.numpy(), g["logits"], rtol=0, atol=2e-6)
+
+
+def test_schedules(golden_dir):
+    g = load(golden_dir, "schedules.npz")
+    assert R.MSA_ALPHABET == str(g["alphabet"]) and R.MASK_ID == int(g["mask_id"]) == 28
+    assert R.Tokenizer().K == int(g["K_msa"]) == 27
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blosum = os.path.join(here, "evodiff_amd", "data", "blosum62-special-MSA.mat")
+    tb = R.Tokenizer(path_to_blosum=blosum, sequences=True)
+    assert tb.K == int(g["K"]) == 26
+    np.testing.assert_array_equal(tb.q_blosum().numpy(), g["blosum_q"])
+    Qbar, Q = tb.q_blosum_schedule(timesteps=500)
+    rows = g["rows"]
+    np.testing.assert_array_equal(Q.numpy()[rows], g["blosum_Q"])
+    np.testing.assert_array_equal(Qbar.numpy()[rows], g["blosum_Qbar"])
+    assert arr_digest(Q.numpy()) == str(g["blosum_Q_sha"])
+    assert arr_digest(Qbar.numpy()) == str(g["blosum_Qbar_sha"])
+    Ubar, U = R.Tokenizer(sequences=True).q_random_schedule(timesteps=500)
+    np.testing.assert_array_equal(U.numpy()[rows], g["uniform_Q"])
+    assert arr_digest(U.numpy()) == str(g["uniform_Q_sha"])
+    assert arr_digest(Ubar.numpy()) == str(g["uniform_Qbar_sha"])
+
+
+def test_oadm_trace(golden_dir):
+    """generate_oaardm executed by the reference vs the oracle's loop: same order, same uniforms."""
+    g = load(golden_dir, "oadm_trace.npz")
+    m = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        m.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])
+    trace = []
+    order, uni = g["order"], torch.from_numpy(g["uniforms"])
+    out = R.generate_oaardm_ref(m, len(order), 2, order, uni, trace=trace)
+    assert np.array_equal(out.numpy(), g["final"])
+    assert [R.Tokenizer().untokenize(s) for s in out] == [str(s) for s in g["strings"]]
+    np.testing.assert_allclose(torch.stack([t["p"] for t in trace]).numpy(), g["p"], atol=1e-6)
+    assert np.array_equal(torch.stack([t["sample"][:, t["pos"]] for t in trace]).numpy(), g["tok"])
+
+
+@pytest.mark.parametrize("tag", ["blosum", "uniform"])
+def test_d3pm_trace(golden_dir, tag):
+    g = load(golden_dir, f"d3pm_trace_{tag}.npz")
+    m = R.build_model(TINY, 500, 13)
+    with torch.no_grad():
+        m.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if tag == "blosum":
+        tok = R.Tokenizer(path_to_blosum=os.path.join(here, "evodiff_amd", "data", "blosum62-special-MSA.mat"),
+                          sequences=True)
+        Qbar, Q = tok.q_blosum_schedule(timesteps=500)
+    else:
+        tok = R.Tokenizer(sequences=True)
+        Qbar, Q = tok.q_random_schedule(timesteps=500)
+    trace = []
+    out = R.generate_d3pm_ref(m, Q, Qbar, 500, torch.from_numpy(g["start"]), torch.from_numpy(g["uniforms"]),
+                              K=tok.K, trace=trace)
+    assert np.array_equal(out.numpy(), g["final"])
+    toks = np.stack([t["sample"].numpy() for t in trace[:-1]])
+    assert np.array_equal(toks, g["toks"])
+    for j, s in enumerate(g["keep"]):
+        np.testing.assert_allclose(trace[int(s)]["post"].numpy(), g["post"][j], rtol=1e-9, atol=1e-12)
+    # t == 1: restricted draw over the first K-6 categories (un-normalised slice of the posterior)
+    np.testing.assert_allclose(trace[-1]["post"][..., :tok.K - 6].numpy(), g["last_post"], rtol=1e-9, atol=1e-12)
+
+
+def test_inverse_cdf_edges():
+    p = torch.tensor([[0.25, 0.25, 0.5], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]])
+    idx, _ = R.inverse_cdf(p, torch.tensor([0.0, 0.0, 0.999999]))
+    assert idx.tolist() == [0, 1, 0]
+    idx, _ = R.inverse_cdf(p, torch.tensor([0.25, 0.5, 0.5]))
+    assert idx.tolist() == [1, 1, 0]
+    # clamp: u*total == total can only happen through rounding; never index past the end
+    idx, _ = R.inverse_cdf(torch.tensor([[0.5, 0.5]]), torch.tensor([1.0]))
+    assert idx.tolist() == [1]
+
+
+def test_f_eff_matches_survey():
+    # 640M L=256 → 1147.5 MFLOP per token-forward; 38M L=100 → 63.98
+    assert abs(R.f_eff_per_sequence(R.MODEL_CONFIGS["640M"], 256) / 256 / 1e6 - 1147.5) < 0.5
+    assert abs(R.f_eff_per_sequence(R.MODEL_CONFIGS["38M"], 100) / 100 / 1e6 - 63.98) < 0.05
