@@ -1,0 +1,659 @@
+// C ABI of libevodiff_hip.so (declared in include/evodiff_hip.h): model handle, weight packing,
+// workspace, per-step launch sequence, hipGraph capture/replay and the HIP-event probe.
+#include "../../include/evodiff_hip.h"
+#include "kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+using namespace ed;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(ED_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                          \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+struct LayerW {
+  int dilation;
+  const float *ln1_g, *ln1_b, *b1, *ln2_g, *ln2_b, *bc, *ln3_g, *ln3_b, *b2;  // fp32 vectors
+  const float *w1_f, *wc_f, *w2_f;                                            // fp32 matrices
+  const bf16_t *w1_h, *wc_h, *w2_h;                                           // bf16 matrices
+};
+
+struct GraphKey {
+  int mode, B, L, prec, n;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(mode, B, L, prec, n) < std::tie(o.mode, o.B, o.L, o.prec, o.n);
+  }
+};
+
+struct PendingEvent {
+  hipEvent_t a, b;
+  int kind;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct ed_model {
+  ed_config cfg;
+  int device = 0;
+  bool committed = false;
+  int64_t n_params = 0;
+  std::unordered_map<std::string, std::vector<float>> staged;
+
+  DevBuf w32, w16;  // packed weight images
+  const float *emb = nullptr, *up_w = nullptr, *up_b = nullptr, *pe = nullptr;
+  const float *last_g = nullptr, *last_b = nullptr, *dec_w = nullptr, *dec_b = nullptr;
+  std::vector<LayerW> layers;
+
+  // workspace
+  int ws_B = 0, ws_L = 0;
+  DevBuf X, Abuf, Ybuf, state, tok, order, uni, qbuf, tvec;
+  hipStream_t cap_stream = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+
+  // probe
+  int probe_every = 0;
+  bool probing_now = false;
+  std::vector<PendingEvent> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+  hipStream_t probe_stream = nullptr;
+
+  ~ed_model() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& e : event_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
+  void drop_graphs() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
+  }
+};
+
+namespace {
+
+std::vector<int> dilations(const ed_config& c) {
+  int period = 1;
+  while ((1 << period) <= c.r) ++period;  // int(log2(r)) + 1   (model.py:108)
+  std::vector<int> d(c.n_layers);
+  for (int n = 0; n < c.n_layers; ++n) d[n] = 1 << (n % period);
+  return d;
+}
+
+struct TensorSpec {
+  std::string key;
+  int64_t numel;
+};
+
+std::vector<TensorSpec> expected_tensors(const ed_config& c) {
+  const int64_t D = c.d_model, H = c.d_hidden, E = c.d_embed, V = c.n_tokens, KS = c.kernel_size;
+  std::vector<TensorSpec> t;
+  t.push_back({"embedder.embedder.weight", V * E});
+  t.push_back({"embedder.up_embedder.conv.weight", D * E});
+  t.push_back({"embedder.up_embedder.conv.bias", D});
+  for (int i = 0; i < c.n_layers; ++i) {
+    const std::string p = "embedder.layers." + std::to_string(i) + ".";
+    t.push_back({p + "conv.weight", H * H * KS});
+    t.push_back({p + "conv.bias", H});
+    t.push_back({p + "sequence1.0.weight", D});
+    t.push_back({p + "sequence1.0.bias", D});
+    t.push_back({p + "sequence1.2.conv.weight", H * D});
+    t.push_back({p + "sequence1.2.conv.bias", H});
+    t.push_back({p + "sequence1.3.weight", H});
+    t.push_back({p + "sequence1.3.bias", H});
+    t.push_back({p + "sequence2.0.weight", H});
+    t.push_back({p + "sequence2.0.bias", H});
+    t.push_back({p + "sequence2.2.conv.weight", D * H});
+    t.push_back({p + "sequence2.2.conv.bias", D});
+  }
+  t.push_back({"last_norm.weight", D});
+  t.push_back({"last_norm.bias", D});
+  t.push_back({"decoder.conv.weight", V * D});
+  t.push_back({"decoder.conv.bias", V});
+  return t;
+}
+
+inline int64_t align64(int64_t n) { return (n + 63) & ~(int64_t)63; }  // element offsets: keep 256-B alignment
+
+// ------------------------------------------------------------------------------------------------
+// probe helpers
+// ------------------------------------------------------------------------------------------------
+struct Probe {
+  ed_model* m;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  Probe(ed_model* m_, hipStream_t s_) : m(m_), s(s_), on(m_->probing_now) {}
+  hipError_t begin() {
+    if (!on) return hipSuccess;
+    if (!m->event_pool.empty()) {
+      a = m->event_pool.back().first;
+      b = m->event_pool.back().second;
+      m->event_pool.pop_back();
+    } else {
+      hipError_t e = hipEventCreate(&a);
+      if (e != hipSuccess) return e;
+      e = hipEventCreate(&b);
+      if (e != hipSuccess) return e;
+    }
+    return hipEventRecord(a, s);
+  }
+  hipError_t end(int kind, double flops, double bytes) {
+    if (!on) return hipSuccess;
+    hipError_t e = hipEventRecord(b, s);
+    m->pending.push_back({a, b, kind, flops, bytes});
+    return e;
+  }
+};
+
+#define LAUNCH_TRY(expr)                                                                                 \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return fail(ED_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                                      __FILE__, __LINE__);                                               \
+  } while (0)
+
+int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
+  Probe pr(m, s);
+  LAUNCH_TRY(pr.begin());
+  if (p.a_bf16 && gemm_bf16_supported(p)) LAUNCH_TRY(launch_gemm_bf16(p, s));
+  else LAUNCH_TRY(launch_gemm_generic(p, s));
+  double taps = 0;
+  for (int t = 0; t < p.ntaps; ++t) {
+    const long off = std::labs((long)(t - p.ntaps / 2) * p.dilation);
+    taps += off < p.L ? (double)(p.L - off) : 0.0;
+  }
+  const double flops = 2.0 * p.B * taps * p.N * (double)p.K;
+  const double esz = p.a_bf16 ? 2.0 : 4.0;
+  const double rows = (double)p.B * p.L;
+  const double bytes = rows * p.K * esz + (double)p.ntaps * p.N * p.K * esz +
+                       rows * p.N * (p.out_bf16 ? 2.0 : 4.0) + (p.resid ? rows * p.N * 4.0 : 0.0);
+  LAUNCH_TRY(pr.end(kind, flops, bytes));
+  return ED_OK;
+}
+
+int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, const float* g, const float* b,
+           int rows, int C, int L, int act, hipStream_t s) {
+  Probe pr(m, s);
+  LAUNCH_TRY(pr.begin());
+  LAUNCH_TRY(launch_ln_act(in, in_bf16, out, out_bf16, g, b, rows, C, L, L, 0, act, s));
+  LAUNCH_TRY(pr.end(ED_K_LNACT, 0.0, (double)rows * C * ((in_bf16 ? 2.0 : 4.0) + (out_bf16 ? 2.0 : 4.0))));
+  return ED_OK;
+}
+
+int ensure_workspace(ed_model* m, int B, int L) {
+  const ed_config& c = m->cfg;
+  const size_t rows = (size_t)B * L + 256;  // slack rows: tile loads may run past the last sequence
+  const size_t Cmax = (size_t)std::max(c.d_model, c.d_hidden);
+  bool grew = false;
+  auto need = [&](DevBuf& b, size_t n) -> hipError_t {
+    if (n > b.bytes) grew = true;
+    return b.ensure(n);
+  };
+  HIP_TRY(need(m->X, rows * c.d_model * 4));
+  HIP_TRY(need(m->Abuf, rows * Cmax * 4));
+  HIP_TRY(need(m->Ybuf, rows * (size_t)c.d_hidden * 4));
+  HIP_TRY(need(m->tok, (size_t)B * L * 8));
+  HIP_TRY(need(m->tvec, (size_t)B * 8));
+  HIP_TRY(need(m->state, 256));
+  if (grew) m->drop_graphs();  // captured graphs hold the old pointers
+  m->ws_B = B;
+  m->ws_L = L;
+  return ED_OK;
+}
+
+// The block stack: X (fp32 residual stream) is updated in place.  model.py:142-147 + ByteNetBlock.
+int run_blocks(ed_model* m, int B, int L, int prec, float* acts, hipStream_t s) {
+  const ed_config& c = m->cfg;
+  const int rows = B * L, D = c.d_model, H = c.d_hidden;
+  const bool h = prec == ED_PREC_BF16;
+  const int act = c.activation == 1 ? 1 : 2;
+  float* X = m->X.as<float>();
+  void* A = m->Abuf.p;
+  void* Y = m->Ybuf.p;
+  const bool y_bf16 = false;  // GEMM1 / conv results feed a LayerNorm: kept fp32 in both precisions
+  for (int i = 0; i < c.n_layers; ++i) {
+    const LayerW& w = m->layers[i];
+    int rc;
+    if ((rc = run_ln(m, X, false, A, h, w.ln1_g, w.ln1_b, rows, D, L, act, s))) return rc;
+    GemmProblem g1{A, L, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, B, L, H, D, 1, 1, h, y_bf16};
+    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
+    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln2_g, w.ln2_b, rows, H, L, act, s))) return rc;
+    GemmProblem gc{A, L, 0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr, B, L, H, H,
+                   c.kernel_size, w.dilation, h, y_bf16};
+    if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows, H, L, act, s))) return rc;
+    GemmProblem g2{A, L, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, X, X, B, L, D, H, 1, 1, h, false};
+    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s))) return rc;
+    if (acts)
+      HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows * D, X, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return ED_OK;
+}
+
+int run_embed(ed_model* m, const int64_t* tokens, const int64_t* tvec, int B, int L, hipStream_t s) {
+  const ed_config& c = m->cfg;
+  Probe pr(m, s);
+  LAUNCH_TRY(pr.begin());
+  LAUNCH_TRY(launch_embed(tokens, tvec, m->state.as<StepState>(), m->emb, c.timesteps > 0 ? m->pe : nullptr,
+                          c.timesteps, m->up_w, m->up_b, m->X.as<float>(), B * L, B, c.d_model, c.d_embed,
+                          c.n_tokens, s));
+  LAUNCH_TRY(pr.end(ED_K_EMBED, 2.0 * B * L * c.d_embed * c.d_model, (double)B * L * (8 + c.d_model * 4.0)));
+  return ED_OK;
+}
+
+int check_shape(const ed_model* m, int B, int L, int prec) {
+  if (!m) return fail(ED_EINVAL, "null model handle");
+  if (!m->committed) return fail(ED_ESTATE, "ed_model_commit has not been called");
+  if (B <= 0 || L <= 0) return fail(ED_EINVAL, "B and L must be positive (got B=%d L=%d)", B, L);
+  if ((int64_t)B * L > (1 << 30)) return fail(ED_EINVAL, "B*L too large");
+  if (prec != ED_PREC_FP32 && prec != ED_PREC_BF16) return fail(ED_EINVAL, "unknown precision %d", prec);
+  return ED_OK;
+}
+
+enum { MODE_OADM = 0, MODE_D3PM = 1 };
+
+// One sampling step on the model-owned buffers (tok/order/uni/qbuf/state).
+int run_step(ed_model* m, int mode, int B, int L, int n, int prec, float* probs, double* post, hipStream_t s) {
+  const ed_config& c = m->cfg;
+  int rc;
+  if ((rc = run_embed(m, m->tok.as<int64_t>(), nullptr, B, L, s))) return rc;
+  if ((rc = run_blocks(m, B, L, prec, nullptr, s))) return rc;
+  Probe pr(m, s);
+  LAUNCH_TRY(pr.begin());
+  if (mode == MODE_OADM) {
+    LAUNCH_TRY(launch_final_oadm(m->X.as<float>(), m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),
+                                 m->order.as<int>(), m->uni.as<float>(), m->state.as<StepState>(), probs, B, L,
+                                 c.d_model, n, s));
+    LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * n * c.d_model, (double)B * c.d_model * 4.0));
+  } else {
+    const size_t kk = (size_t)c.timesteps * n * n;
+    LAUNCH_TRY(launch_final_d3pm(m->X.as<float>(), m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),
+                                 m->qbuf.as<double>(), m->qbuf.as<double>() + kk, m->uni.as<float>(),
+                                 m->state.as<StepState>(), post, B, L, c.d_model, n, c.timesteps, s));
+    LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * L * n * (c.d_model + 2.0 * n), (double)B * L * c.d_model * 4.0));
+  }
+  LAUNCH_TRY(launch_advance_step(m->state.as<StepState>(), s));
+  return ED_OK;
+}
+
+int get_graph(ed_model* m, int mode, int B, int L, int n, int prec, float* probs, double* post,
+              hipGraphExec_t* out) {
+  // trace buffers are caller-owned: graphs are only cached for the trace-free form
+  const GraphKey key{mode, B, L, prec, n};
+  auto it = m->graphs.find(key);
+  if (it != m->graphs.end()) {
+    *out = it->second;
+    return ED_OK;
+  }
+  if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+  const bool was = m->probing_now;
+  m->probing_now = false;
+  int rc = run_step(m, mode, B, L, n, prec, probs, post, m->cap_stream);
+  m->probing_now = was;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess) return fail(ED_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(ED_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  m->graphs[key] = exec;
+  *out = exec;
+  return ED_OK;
+}
+
+int run_loop(ed_model* m, int mode, int B, int L, int n, int n_steps, int prec, int use_graph, float* probs,
+             double* post, hipStream_t s) {
+  hipGraphExec_t exec = nullptr;
+  const bool traced = probs != nullptr || post != nullptr;
+  if (use_graph && !traced) {
+    int rc = get_graph(m, mode, B, L, n, prec, nullptr, nullptr, &exec);
+    if (rc) return rc;
+  }
+  for (int step = 0; step < n_steps; ++step) {
+    const bool probe = m->probe_every > 0 && (step % m->probe_every) == 0;
+    if (exec && !probe) {
+      HIP_TRY(hipGraphLaunch(exec, s));
+    } else {
+      m->probing_now = probe;
+      int rc = run_step(m, mode, B, L, n, prec, probs, post, s);
+      m->probing_now = false;
+      if (rc) return rc;
+    }
+  }
+  return ED_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int ed_abi_version(void) { return ED_ABI_VERSION; }
+const char* ed_last_error(void) { return g_err.c_str(); }
+
+int ed_model_create(const ed_config* cfg, int device, ed_model** out) {
+  if (!cfg || !out) return fail(ED_EINVAL, "null argument");
+  const ed_config& c = *cfg;
+  if (c.n_tokens < 2 || c.n_tokens > 64) return fail(ED_EINVAL, "n_tokens must be in [2, 64]");
+  if (c.d_embed < 1 || c.d_embed > 16) return fail(ED_EINVAL, "d_embed must be in [1, 16]");
+  if (c.d_model < 32 || c.d_model > 2048 || c.d_model % 32) return fail(ED_EINVAL, "d_model must be a multiple of 32 in [32, 2048]");
+  if (c.d_hidden < 32 || c.d_hidden > 2048 || c.d_hidden % 32) return fail(ED_EINVAL, "d_hidden must be a multiple of 32 in [32, 2048]");
+  if (c.n_layers < 1 || c.n_layers > 1024) return fail(ED_EINVAL, "n_layers out of range");
+  if (c.kernel_size < 1 || c.kernel_size > 9 || !(c.kernel_size & 1)) return fail(ED_EINVAL, "kernel_size must be odd, <= 9");
+  if (c.r < 1 || c.r > 4096) return fail(ED_EINVAL, "r out of range");
+  if (c.timesteps < 0 || c.timesteps > 100000) return fail(ED_EINVAL, "timesteps out of range");
+  if (c.activation != 0 && c.activation != 1) return fail(ED_EINVAL, "activation must be 0 (relu) or 1 (gelu)");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(ED_EINVAL, "device %d not present (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  ed_model* m = new (std::nothrow) ed_model();
+  if (!m) return fail(ED_ENOMEM, "out of host memory");
+  m->cfg = c;
+  m->device = device;
+  *out = m;
+  return ED_OK;
+}
+
+void ed_model_destroy(ed_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  delete m;
+}
+
+int ed_model_load_tensor(ed_model* m, const char* key, const float* host, int64_t numel) {
+  if (!m || !key || !host) return fail(ED_EINVAL, "null argument");
+  const std::string k(key);
+  int64_t want = -1;
+  if (k == "time_encoding.table") want = (int64_t)m->cfg.timesteps * m->cfg.d_embed;
+  else
+    for (const auto& t : expected_tensors(m->cfg))
+      if (t.key == k) { want = t.numel; break; }
+  if (want < 0) return fail(ED_EINVAL, "unexpected tensor key '%s'", key);
+  if (want != numel) return fail(ED_EINVAL, "tensor '%s' has %lld elements, expected %lld", key, (long long)numel, (long long)want);
+  m->staged[k].assign(host, host + numel);
+  m->committed = false;
+  return ED_OK;
+}
+
+int ed_model_commit(ed_model* m) {
+  if (!m) return fail(ED_EINVAL, "null model handle");
+  const ed_config& c = m->cfg;
+  HIP_TRY(hipSetDevice(m->device));
+  const auto specs = expected_tensors(c);
+  for (const auto& t : specs)
+    if (!m->staged.count(t.key)) return fail(ED_ESTATE, "missing tensor '%s'", t.key.c_str());
+  if (c.timesteps > 0 && !m->staged.count("time_encoding.table")) return fail(ED_ESTATE, "missing tensor 'time_encoding.table'");
+
+  const int64_t D = c.d_model, H = c.d_hidden, KS = c.kernel_size;
+  // layout pass: fp32 image holds everything; bf16 image holds the three matrices per layer
+  int64_t n32 = 0, n16 = 0;
+  auto take32 = [&](int64_t n) { int64_t o = n32; n32 += align64(n); return o; };
+  auto take16 = [&](int64_t n) { int64_t o = n16; n16 += align64(n); return o; };
+  std::vector<float> img32;
+  std::vector<bf16_t> img16;
+  struct Place { int64_t off; const std::vector<float>* src; };
+  std::vector<Place> vec_places;
+  auto stage_vec = [&](const std::string& key) {
+    const auto& v = m->staged[key];
+    int64_t o = take32((int64_t)v.size());
+    vec_places.push_back({o, &v});
+    return o;
+  };
+  m->n_params = 0;
+  for (const auto& t : specs) m->n_params += t.numel;
+
+  const int64_t o_emb = stage_vec("embedder.embedder.weight");
+  const int64_t o_upw = stage_vec("embedder.up_embedder.conv.weight");
+  const int64_t o_upb = stage_vec("embedder.up_embedder.conv.bias");
+  const int64_t o_lg = stage_vec("last_norm.weight");
+  const int64_t o_lb = stage_vec("last_norm.bias");
+  const int64_t o_dw = stage_vec("decoder.conv.weight");
+  const int64_t o_db = stage_vec("decoder.conv.bias");
+  const int64_t o_pe = c.timesteps > 0 ? stage_vec("time_encoding.table") : -1;
+  struct LOff { int64_t ln1g, ln1b, b1, ln2g, ln2b, bc, ln3g, ln3b, b2, w1, wc, w2, w1h, wch, w2h; };
+  std::vector<LOff> lo(c.n_layers);
+  for (int i = 0; i < c.n_layers; ++i) {
+    const std::string p = "embedder.layers." + std::to_string(i) + ".";
+    LOff& o = lo[i];
+    o.ln1g = stage_vec(p + "sequence1.0.weight");
+    o.ln1b = stage_vec(p + "sequence1.0.bias");
+    o.b1 = stage_vec(p + "sequence1.2.conv.bias");
+    o.ln2g = stage_vec(p + "sequence1.3.weight");
+    o.ln2b = stage_vec(p + "sequence1.3.bias");
+    o.bc = stage_vec(p + "conv.bias");
+    o.ln3g = stage_vec(p + "sequence2.0.weight");
+    o.ln3b = stage_vec(p + "sequence2.0.bias");
+    o.b2 = stage_vec(p + "sequence2.2.conv.bias");
+    o.w1 = stage_vec(p + "sequence1.2.conv.weight");   // (H, D, 1) == [N=H][K=D]
+    o.w2 = stage_vec(p + "sequence2.2.conv.weight");   // (D, H, 1) == [N=D][K=H]
+    o.wc = take32(H * H * KS);                          // repacked below: (H, H, KS) -> [tap][N][K]
+    o.w1h = take16(H * D);
+    o.w2h = take16(D * H);
+    o.wch = take16(H * H * KS);
+  }
+  img32.assign((size_t)n32, 0.f);
+  img16.assign((size_t)n16, 0);
+  for (const auto& pl : vec_places) std::memcpy(img32.data() + pl.off, pl.src->data(), pl.src->size() * 4);
+  for (int i = 0; i < c.n_layers; ++i) {
+    const std::string p = "embedder.layers." + std::to_string(i) + ".";
+    const auto& wc = m->staged[p + "conv.weight"];
+    float* dst = img32.data() + lo[i].wc;
+    for (int64_t o = 0; o < H; ++o)
+      for (int64_t ch = 0; ch < H; ++ch)
+        for (int64_t t = 0; t < KS; ++t) dst[(t * H + o) * H + ch] = wc[(o * H + ch) * KS + t];
+    const float* s1 = img32.data() + lo[i].w1;
+    const float* s2 = img32.data() + lo[i].w2;
+    for (int64_t j = 0; j < H * D; ++j) img16[lo[i].w1h + j] = f32_to_bf16_bits(s1[j]);
+    for (int64_t j = 0; j < D * H; ++j) img16[lo[i].w2h + j] = f32_to_bf16_bits(s2[j]);
+    for (int64_t j = 0; j < H * H * KS; ++j) img16[lo[i].wch + j] = f32_to_bf16_bits(dst[j]);
+  }
+  HIP_TRY(m->w32.ensure((size_t)n32 * 4));
+  HIP_TRY(m->w16.ensure((size_t)n16 * 2 + 256));
+  HIP_TRY(hipMemcpy(m->w32.p, img32.data(), (size_t)n32 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->w16.p, img16.data(), (size_t)n16 * 2, hipMemcpyHostToDevice));
+  const float* b32 = m->w32.as<float>();
+  const bf16_t* b16 = m->w16.as<bf16_t>();
+  m->emb = b32 + o_emb; m->up_w = b32 + o_upw; m->up_b = b32 + o_upb;
+  m->last_g = b32 + o_lg; m->last_b = b32 + o_lb; m->dec_w = b32 + o_dw; m->dec_b = b32 + o_db;
+  m->pe = o_pe >= 0 ? b32 + o_pe : nullptr;
+  const auto dil = dilations(c);
+  m->layers.resize(c.n_layers);
+  for (int i = 0; i < c.n_layers; ++i) {
+    const LOff& o = lo[i];
+    m->layers[i] = LayerW{dil[i], b32 + o.ln1g, b32 + o.ln1b, b32 + o.b1, b32 + o.ln2g, b32 + o.ln2b, b32 + o.bc,
+                          b32 + o.ln3g, b32 + o.ln3b, b32 + o.b2, b32 + o.w1, b32 + o.wc, b32 + o.w2,
+                          b16 + o.w1h, b16 + o.wch, b16 + o.w2h};
+  }
+  m->staged.clear();
+  m->drop_graphs();
+  m->committed = true;
+  return ED_OK;
+}
+
+int64_t ed_model_num_params(const ed_model* m) { return m ? m->n_params : 0; }
+
+int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
+                       float* logits_dev, float* acts_dev, int precision, void* stream) {
+  int rc = check_shape(m, B, L, precision);
+  if (rc) return rc;
+  if (!tokens_dev || !logits_dev) return fail(ED_EINVAL, "null tokens/logits pointer");
+  if (m->cfg.timesteps > 0 && !timesteps_dev) return fail(ED_EINVAL, "timesteps_dev is required for a model with timestep encoding");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(m->device));
+  if ((rc = ensure_workspace(m, B, L))) return rc;
+  m->probing_now = m->probe_every > 0;
+  rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, s);
+  if (!rc && acts_dev)
+    HIP_TRY(hipMemcpyAsync(acts_dev, m->X.p, (size_t)B * L * m->cfg.d_model * 4, hipMemcpyDeviceToDevice, s));
+  if (!rc) rc = run_blocks(m, B, L, precision, acts_dev, s);
+  if (!rc) {
+    Probe pr(m, s);
+    LAUNCH_TRY(pr.begin());
+    LAUNCH_TRY(launch_final_logits(m->X.as<float>(), m->last_g, m->last_b, m->dec_w, m->dec_b, logits_dev, B * L,
+                                   m->cfg.d_model, m->cfg.n_tokens, s));
+    LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * L * m->cfg.n_tokens * m->cfg.d_model, (double)B * L * m->cfg.d_model * 4.0));
+  }
+  m->probing_now = false;
+  return rc;
+}
+
+int ed_forward(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
+               float* logits_dev, int precision, void* stream) {
+  return ed_forward_collect(m, tokens_dev, timesteps_dev, B, L, logits_dev, nullptr, precision, stream);
+}
+
+int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, const float* uniforms_dev, int B,
+                   int L, int n_steps, int n_draw, float* probs_dev, int precision, int use_graph, void* stream) {
+  int rc = check_shape(m, B, L, precision);
+  if (rc) return rc;
+  if (!tokens_dev || !order_dev || !uniforms_dev) return fail(ED_EINVAL, "null tokens/order/uniforms pointer");
+  if (n_steps < 0 || n_steps > (1 << 24)) return fail(ED_EINVAL, "n_steps out of range");
+  if (n_draw < 1 || n_draw > m->cfg.n_tokens) return fail(ED_EINVAL, "n_draw must be in [1, n_tokens]");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(m->device));
+  if ((rc = ensure_workspace(m, B, L))) return rc;
+  if (n_steps == 0) return ED_OK;
+  // positions are validated on the host before any kernel indexes with them
+  std::vector<int32_t> ord((size_t)n_steps);
+  HIP_TRY(hipMemcpyAsync(ord.data(), order_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n_steps; ++i)
+    if (ord[i] < 0 || ord[i] >= L) return fail(ED_EINVAL, "order[%d] = %d is outside [0, %d)", i, ord[i], L);
+  {
+    const size_t ob = m->order.bytes, ub = m->uni.bytes;
+    HIP_TRY(m->order.ensure((size_t)n_steps * 4));
+    HIP_TRY(m->uni.ensure((size_t)n_steps * B * 4));
+    if (m->order.bytes != ob || m->uni.bytes != ub) m->drop_graphs();
+  }
+  HIP_TRY(hipMemcpyAsync(m->order.p, order_dev, (size_t)n_steps * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)n_steps * B * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
+  if ((rc = run_loop(m, MODE_OADM, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  return ED_OK;
+}
+
+int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const double* Qbar_dev,
+                   const float* uniforms_dev, int B, int L, int K, int t_start, int n_steps, double* post_dev,
+                   int precision, int use_graph, void* stream) {
+  int rc = check_shape(m, B, L, precision);
+  if (rc) return rc;
+  const int T = m->cfg.timesteps;
+  if (T <= 1) return fail(ED_ESTATE, "model was created without timestep encoding (cfg.timesteps = %d)", T);
+  if (!tokens_dev || !Q_dev || !Qbar_dev || !uniforms_dev) return fail(ED_EINVAL, "null tokens/Q/Qbar/uniforms pointer");
+  if (K < 7 || K > m->cfg.n_tokens || K > 62) return fail(ED_EINVAL, "K must be in [7, n_tokens]");
+  if (t_start < 1 || t_start > T - 1) return fail(ED_EINVAL, "t_start must be in [1, timesteps-1]");
+  if (n_steps < 0 || n_steps > t_start) return fail(ED_EINVAL, "n_steps must be in [0, t_start] (t runs down to 1)");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(m->device));
+  if ((rc = ensure_workspace(m, B, L))) return rc;
+  if (n_steps == 0) return ED_OK;
+  // x_t indexes Q's columns: validate the token range on the host first
+  {
+    std::vector<int64_t> tk((size_t)B * L);
+    HIP_TRY(hipMemcpyAsync(tk.data(), tokens_dev, tk.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < tk.size(); ++i)
+      if (tk[i] < 0 || tk[i] >= K) return fail(ED_EINVAL, "tokens[%zu] = %lld is outside [0, K=%d)", i, (long long)tk[i], K);
+  }
+  const size_t kk = (size_t)T * K * K;
+  {
+    const size_t qb = m->qbuf.bytes, ub = m->uni.bytes;
+    HIP_TRY(m->qbuf.ensure(2 * kk * 8));
+    HIP_TRY(m->uni.ensure((size_t)T * B * L * 4));
+    if (m->qbuf.bytes != qb || m->uni.bytes != ub) m->drop_graphs();
+  }
+  HIP_TRY(hipMemcpyAsync(m->qbuf.p, Q_dev, kk * 8, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->qbuf.as<double>() + kk, Qbar_dev, kk * 8, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)T * B * L * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  StepState st{0, t_start};
+  HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
+  HIP_TRY(hipMemcpyAsync(m->state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // `st` lives on this stack frame
+  if ((rc = run_loop(m, MODE_D3PM, B, L, K, n_steps, precision, use_graph, nullptr, post_dev, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  return ED_OK;
+}
+
+int ed_probe_config(ed_model* m, int every_n_steps) {
+  if (!m) return fail(ED_EINVAL, "null model handle");
+  if (every_n_steps < 0) return fail(ED_EINVAL, "every_n_steps must be >= 0");
+  m->probe_every = every_n_steps;
+  return ED_OK;
+}
+
+int ed_probe_read(ed_model* m, ed_probe_stat* stats, void* stream) {
+  if (!m || !stats) return fail(ED_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  for (int k = 0; k < ED_K_COUNT; ++k) stats[k] = ed_probe_stat{0.0, 0.0, 0.0, 0};
+  for (auto& p : m->pending) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+    stats[p.kind].ms += ms;
+    stats[p.kind].flops += p.flops;
+    stats[p.kind].bytes += p.bytes;
+    stats[p.kind].launches += 1;
+    m->event_pool.push_back({p.a, p.b});
+  }
+  m->pending.clear();
+  return ED_OK;
+}
+
+}  // extern "C"

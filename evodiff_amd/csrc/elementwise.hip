@@ -1,0 +1,375 @@
+// Row-wise kernels of the ByteNetLMTime step (gfx950): embedding + timestep encoding + up-projection,
+// LayerNorm + activation, and the three step tails (full logits, OA-DM draw, D3PM posterior draw).
+// All are HBM-bound: one 64-lane wave owns one row, loads are 16 bytes (fp32) / 8 bytes (bf16) per lane,
+// statistics are reduced with cross-lane shuffles, nothing is staged through LDS except small tables.
+#include "kernels.hpp"
+
+namespace ed {
+namespace {
+
+constexpr float LN_EPS = 1e-5f;  // nn.LayerNorm default, as constructed in ByteNetBlock / model.py:166
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------------------
+// embed: evodiff/model.py:131-140
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const int64_t* tvec,
+                                                    const StepState* state, const float* __restrict__ emb,
+                                                    const float* __restrict__ pe, int n_timesteps,
+                                                    const float* __restrict__ up_w, const float* __restrict__ up_b,
+                                                    float* __restrict__ X, int rows, int B, int D, int E,
+                                                    int n_tokens) {
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  long tok = tokens[row];
+  if (tok < 0 || tok >= n_tokens) tok = n_tokens - 1;  // host validates; never index out of the table
+  float e[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) e[j] = j < E ? emb[tok * E + j] : 0.f;
+  if (pe != nullptr) {
+    // quirk Q1 (model.py:136-137): expand(L,B,E).reshape(B,L,E) => row r receives pe[y[r % B]]
+    long t = tvec ? tvec[row % B] : (long)(state->t_start - state->step);
+    if (t < 0) t = 0;
+    if (t >= n_timesteps) t = n_timesteps - 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < E) e[j] = pe[t * E + j] + e[j];
+  }
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < E) acc = fmaf(up_w[c * E + j], e[j], acc);
+    X[(long)row * D + c] = acc + up_b[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm (+ activation), one wave per row, NCH chunks of 256 channels held in registers.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH, bool IN_BF16>
+__device__ __forceinline__ void load_row(const void* in, long row, int C, int lane, float (&v)[NCH][4]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = (c * 64 + lane) * 4;
+    if (idx < C) {
+      if constexpr (IN_BF16) {
+        const uint2 raw = *(const uint2*)((const bf16_t*)in + row * C + idx);
+        v[c][0] = __uint_as_float(raw.x << 16);
+        v[c][1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[c][2] = __uint_as_float(raw.y << 16);
+        v[c][3] = __uint_as_float(raw.y & 0xffff0000u);
+      } else {
+        const float4 raw = *(const float4*)((const float*)in + row * C + idx);
+        v[c][0] = raw.x; v[c][1] = raw.y; v[c][2] = raw.z; v[c][3] = raw.w;
+      }
+    } else {
+      v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+    }
+  }
+}
+
+// (v - mean) * rstd in place; mean and biased variance over C as nn.LayerNorm computes them.
+template <int NCH>
+__device__ __forceinline__ void normalize_row(float (&v)[NCH][4], int C, int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const bool on = (c * 64 + lane) * 4 < C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = on ? v[c][j] - mean : 0.f;
+      v[c][j] = d;
+      q = fmaf(d, d, q);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + LN_EPS);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[c][j] *= rstd;
+}
+
+template <int NCH, bool IN_BF16, bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int rows, int C, int L, long out_pitch, long out_row0, int act) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NCH][4];
+  load_row<NCH, IN_BF16>(in, row, C, lane, v);
+  normalize_row<NCH>(v, C, lane);
+  const long orow = (row / L) * out_pitch + out_row0 + (row % L);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = (c * 64 + lane) * 4;
+    if (idx >= C) continue;
+    const float4 gm = *(const float4*)(gamma + idx);
+    const float4 bt = *(const float4*)(beta + idx);
+    float y[4] = {fmaf(v[c][0], gm.x, bt.x), fmaf(v[c][1], gm.y, bt.y), fmaf(v[c][2], gm.z, bt.z),
+                  fmaf(v[c][3], gm.w, bt.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (act == 1) y[j] = gelu_exact(y[j]);
+      else if (act == 2) y[j] = fmaxf(y[j], 0.f);
+    }
+    if constexpr (OUT_BF16) {
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16_bits(y[0]) | ((uint32_t)f32_to_bf16_bits(y[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16_bits(y[2]) | ((uint32_t)f32_to_bf16_bits(y[3]) << 16);
+      *(uint2*)((bf16_t*)out + orow * C + idx) = pk;
+    } else {
+      *(float4*)((float*)out + orow * C + idx) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+  }
+}
+
+// last_norm + decoder for one row held by one wave: returns logit k in lane k (k < n_out <= 64).
+template <int NCH>
+__device__ __forceinline__ float row_logits(const float* X, long row, int D, int lane, const float* gamma,
+                                            const float* beta, const float* dec_w, const float* dec_b, int n_out) {
+  float v[NCH][4];
+  load_row<NCH, false>(X, row, D, lane, v);
+  normalize_row<NCH>(v, D, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = (c * 64 + lane) * 4;
+    if (idx < D) {
+      const float4 gm = *(const float4*)(gamma + idx);
+      const float4 bt = *(const float4*)(beta + idx);
+      v[c][0] = fmaf(v[c][0], gm.x, bt.x); v[c][1] = fmaf(v[c][1], gm.y, bt.y);
+      v[c][2] = fmaf(v[c][2], gm.z, bt.z); v[c][3] = fmaf(v[c][3], gm.w, bt.w);
+    }
+  }
+  float mine = 0.f;
+  for (int k = 0; k < n_out; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = (c * 64 + lane) * 4;
+      if (idx < D) {
+        const float4 w = *(const float4*)(dec_w + (long)k * D + idx);
+        s = fmaf(v[c][0], w.x, s); s = fmaf(v[c][1], w.y, s);
+        s = fmaf(v[c][2], w.z, s); s = fmaf(v[c][3], w.w, s);
+      }
+    }
+    s = wave_sum(s) + dec_b[k];
+    if (lane == k) mine = s;
+  }
+  return mine;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void final_logits_kernel(const float* __restrict__ X, const float* gamma,
+                                                           const float* beta, const float* dec_w, const float* dec_b,
+                                                           float* __restrict__ logits, int rows, int D, int n_tokens) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float mine = row_logits<NCH>(X, row, D, lane, gamma, beta, dec_w, dec_b, n_tokens);
+  if (lane < n_tokens) logits[row * n_tokens + lane] = mine;
+}
+
+// softmax over lanes [0, n): returns p in lane k, computed as exp(x - max) / sum like torch.softmax.
+__device__ __forceinline__ float lane_softmax(float logit, int lane, int n) {
+  const float x = lane < n ? logit : -INFINITY;
+  const float m = wave_max(x);
+  const float e = lane < n ? expf(x - m) : 0.f;
+  return e / wave_sum(e);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// OA-DM tail: generate.py:198-211.  One wave per sequence; only row order[step] is decoded.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(64) void final_oadm_kernel(const float* __restrict__ X, const float* gamma,
+                                                        const float* beta, const float* dec_w, const float* dec_b,
+                                                        int64_t* tokens, const int* __restrict__ order,
+                                                        const float* __restrict__ uniforms, const StepState* state,
+                                                        float* probs, int B, int L, int D, int n_draw) {
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const int step = state->step;
+  const int pos = order[step];
+  const long row = (long)b * L + pos;
+  const float logit = row_logits<NCH>(X, row, D, lane, gamma, beta, dec_w, dec_b, n_draw);
+  const float p = lane_softmax(logit, lane, n_draw);
+  if (probs != nullptr && lane < n_draw) probs[((long)step * B + b) * n_draw + lane] = p;
+  // inverse CDF: index = #{k : cdf[k] <= u * cdf[n-1]}, cdf = left-to-right fp32 running sum
+  float cdf = 0.f, mycdf = 0.f;
+  for (int k = 0; k < n_draw; ++k) {
+    cdf += __shfl(p, k);
+    if (lane == k) mycdf = cdf;
+  }
+  const float thr = uniforms[(long)step * B + b] * cdf;
+  const unsigned long long below = __ballot(lane < n_draw && mycdf <= thr);
+  int idx = __popcll(below);
+  if (idx > n_draw - 1) idx = n_draw - 1;
+  if (lane == 0) tokens[row] = idx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// D3PM tail: generate.py:279-298.  One wave per (sequence, position); Q[t] and Qbar[t-1] (K x K fp64)
+// are staged in LDS once per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void final_d3pm_kernel(const float* __restrict__ X, const float* gamma,
+                                                         const float* beta, const float* dec_w, const float* dec_b,
+                                                         int64_t* tokens, const double* __restrict__ Q,
+                                                         const double* __restrict__ Qbar,
+                                                         const float* __restrict__ uniforms, const StepState* state,
+                                                         double* post, int B, int L, int D, int K, int n_timesteps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sQ = (double*)smem;          // Q[t]       [K][K]
+  double* sQb = sQ + K * K;            // Qbar[t-1]  [K][K]
+  const int step = state->step;
+  const int t = state->t_start - step;
+  for (int i = threadIdx.x; i < K * K; i += 256) {
+    sQ[i] = Q[(long)t * K * K + i];
+    sQb[i] = Qbar[(long)(t - 1) * K * K + i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long rows = (long)B * L;
+  const long row = (long)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  const float logit = row_logits<NCH>(X, row, D, lane, gamma, beta, dec_w, dec_b, K);
+  const double p = (double)lane_softmax(logit, lane, K);
+  const double p2 = p * p;                        // p enters twice (quirk Q3, generate.py:287,289)
+  long xt = tokens[row];
+  if (xt < 0 || xt >= K) xt = K - 1;               // host validates; keep LDS reads in range regardless
+  double marg = 0.0;
+  for (int j = 0; j < K; ++j) {
+    const double pj = __shfl(p2, j);
+    if (lane < K) marg = fma(pj, sQb[j * K + lane], marg);
+  }
+  if (lane < K) marg *= sQ[lane * K + xt];        // A[l,k] = Q_t[k, x_t[l]]  (generate.py:285)
+  // normalise, then inverse CDF, all in fp64 and left to right; every lane walks the same sums
+  double total = 0.0;
+  for (int k = 0; k < K; ++k) total += __shfl(marg, k);
+  const double pk = lane < K ? marg / total : 0.0;
+  if (post != nullptr && lane < K) post[((long)step * rows + row) * K + lane] = pk;
+  const int n = (t == 1) ? K - 6 : K;              // generate.py:293-294: last step draws canonical AAs only
+  const long urow = (t == 1) ? (long)(n_timesteps - 1) : (long)(n_timesteps - 1 - t);
+  double cdf = 0.0, mycdf = 0.0;
+  for (int k = 0; k < n; ++k) {
+    cdf += __shfl(pk, k);
+    if (lane == k) mycdf = cdf;
+  }
+  const double thr = (double)uniforms[urow * rows + row] * cdf;
+  int idx = __popcll(__ballot(lane < n && mycdf <= thr));
+  if (idx > n - 1) idx = n - 1;
+  if (lane == 0) tokens[row] = idx;
+}
+
+__global__ void advance_step_kernel(StepState* s) { s->step += 1; }
+
+}  // namespace
+
+hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepState* state, const float* emb,
+                        const float* pe, int n_timesteps, const float* up_w, const float* up_b, float* X,
+                        int rows, int B, int D, int E, int n_tokens, hipStream_t stream) {
+  if (E > 16 || rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, stream, tokens, tvec, state, emb, pe, n_timesteps,
+                     up_w, up_b, X, rows, B, D, E, n_tokens);
+  return hipGetLastError();
+}
+
+#define ED_NCH_DISPATCH(C, CALL)              \
+  do {                                        \
+    const int nch_ = ((C) + 255) / 256;       \
+    if (nch_ <= 1) { CALL(1); }               \
+    else if (nch_ <= 2) { CALL(2); }          \
+    else if (nch_ <= 4) { CALL(4); }          \
+    else if (nch_ <= 5) { CALL(5); }          \
+    else if (nch_ <= 8) { CALL(8); }          \
+    else return hipErrorInvalidValue;         \
+  } while (0)
+
+hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
+                         const float* beta, int rows, int C, int L, long out_pitch, long out_row0, int act,
+                         hipStream_t stream) {
+  if (C % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define ED_CALL(N)                                                                                            \
+  if (in_bf16 && out_bf16)                                                                                    \
+    hipLaunchKernelGGL((ln_act_kernel<N, true, true>), grid, block, 0, stream, in, out, gamma, beta, rows, C, \
+                       L, out_pitch, out_row0, act);                                                          \
+  else if (in_bf16)                                                                                           \
+    hipLaunchKernelGGL((ln_act_kernel<N, true, false>), grid, block, 0, stream, in, out, gamma, beta, rows,   \
+                       C, L, out_pitch, out_row0, act);                                                       \
+  else if (out_bf16)                                                                                          \
+    hipLaunchKernelGGL((ln_act_kernel<N, false, true>), grid, block, 0, stream, in, out, gamma, beta, rows,   \
+                       C, L, out_pitch, out_row0, act);                                                       \
+  else                                                                                                        \
+    hipLaunchKernelGGL((ln_act_kernel<N, false, false>), grid, block, 0, stream, in, out, gamma, beta, rows,  \
+                       C, L, out_pitch, out_row0, act)
+  ED_NCH_DISPATCH(C, ED_CALL);
+#undef ED_CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_final_logits(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                               const float* dec_b, float* logits, int rows, int D, int n_tokens,
+                               hipStream_t stream) {
+  if (D % 4 != 0 || n_tokens > 64 || rows <= 0) return hipErrorInvalidValue;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define ED_CALL(N) \
+  hipLaunchKernelGGL((final_logits_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, logits, rows, D, n_tokens)
+  ED_NCH_DISPATCH(D, ED_CALL);
+#undef ED_CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_final_oadm(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                             const float* dec_b, int64_t* tokens, const int* order, const float* uniforms,
+                             const StepState* state, float* probs, int B, int L, int D, int n_draw,
+                             hipStream_t stream) {
+  if (D % 4 != 0 || n_draw > 64 || n_draw < 1 || B <= 0) return hipErrorInvalidValue;
+  const dim3 grid(B), block(64);
+#define ED_CALL(N)                                                                                             \
+  hipLaunchKernelGGL((final_oadm_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, tokens, order, \
+                     uniforms, state, probs, B, L, D, n_draw)
+  ED_NCH_DISPATCH(D, ED_CALL);
+#undef ED_CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_final_d3pm(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                             const float* dec_b, int64_t* tokens, const double* Q, const double* Qbar,
+                             const float* uniforms, const StepState* state, double* post, int B, int L, int D,
+                             int K, int n_timesteps, hipStream_t stream) {
+  if (D % 4 != 0 || K > 62 || K < 7 || B <= 0) return hipErrorInvalidValue;
+  const long rows = (long)B * L;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const size_t smem = (size_t)(2 * K * K) * sizeof(double);
+#define ED_CALL(N)                                                                                              \
+  hipLaunchKernelGGL((final_d3pm_kernel<N>), grid, block, smem, stream, X, gamma, beta, dec_w, dec_b, tokens, Q, \
+                     Qbar, uniforms, state, post, B, L, D, K, n_timesteps)
+  ED_NCH_DISPATCH(D, ED_CALL);
+#undef ED_CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_advance_step(StepState* state, hipStream_t stream) {
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, stream, state);
+  return hipGetLastError();
+}
+
+}  // namespace ed

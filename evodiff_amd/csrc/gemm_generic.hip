@@ -1,0 +1,174 @@
+// Generic implicit-GEMM tile kernel for the ByteNet block (gfx950).
+//
+// One kernel serves the 1x1 projections (ntaps = 1) and the dilated k=5 MaskedConv1d
+// (sequence_models MaskedConv1d as called from evodiff/model.py:113-117): the convolution is a GEMM
+// whose K axis runs over (tap, channel) and whose A rows for tap t are the activation rows shifted by
+// (t - ntaps/2) * dilation positions inside the SAME sequence; rows that fall outside [0, L) are
+// zero ('same' padding) and taps whose whole 128-row tile is outside are skipped.
+//
+// This is the correctness-first kernel: 128x128 output tile per 256-thread workgroup (4 waves, each
+// 64x64 as 2x2 MFMA 32x32 tiles), register-staged global->LDS copies with bounds checks, so it takes
+// any B, L, N and any K that is a multiple of one K-step.  It is the fp32 validation path
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) and the fallback for bf16 shapes the tuned kernel
+// in gemm_bf16.hip does not cover.
+#include "kernels.hpp"
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 64;    // bytes of K per tile row per K-step (16 fp32 / 32 bf16)
+constexpr int LDS_STRIDE = 80;   // 64 + 16 pad: the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
+
+template <bool BF16, bool OUT_BF16, bool RESID>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
+  constexpr int ESZ = BF16 ? 2 : 4;
+  constexpr int KSTEP = ROW_BYTES / ESZ;
+  __shared__ __attribute__((aligned(16))) char lds[2 * BM * LDS_STRIDE];
+  char* ldsA = lds;
+  char* ldsB = lds + BM * LDS_STRIDE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int tiles_per_seq = (g.L + BM - 1) / BM;
+  const int b = blockIdx.y / tiles_per_seq;
+  const int l0 = (blockIdx.y % tiles_per_seq) * BM;
+  const int n0 = blockIdx.x * BN;
+
+  // loader role: thread -> (tile row, 32-byte half of the 64-byte K slice)
+  const int lrow = tid >> 1, lhalf = tid & 1;
+  const int ksteps = g.K / KSTEP;
+  const int half_taps = g.ntaps / 2;
+
+  // contiguous range of taps that touch this tile at all
+  int tap_lo = 0, tap_hi = g.ntaps - 1;
+  while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
+  while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
+  const int it_begin = tap_lo * ksteps, it_end = (tap_hi + 1) * ksteps;
+
+  const char* Abase = (const char*)g.A;
+  const char* Wbase = (const char*)g.W;
+  const int nrow = n0 + lrow;
+
+  uint4 ra0, ra1, rb0, rb1;
+  auto gload = [&](int it) {
+    const int tap = it / ksteps;
+    const int kk = (it - tap * ksteps) * KSTEP;
+    const int l = l0 + lrow + (tap - half_taps) * g.dilation;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (l >= 0 && l < g.L) {
+      const char* p = Abase + (((long)b * g.a_seq_pitch + g.a_row0 + l) * g.K + kk) * ESZ + lhalf * 32;
+      ra0 = *(const uint4*)p;
+      ra1 = *(const uint4*)(p + 16);
+    } else {
+      ra0 = z; ra1 = z;
+    }
+    if (nrow < g.N) {
+      const char* p = Wbase + (((long)tap * g.N + nrow) * g.K + kk) * ESZ + lhalf * 32;
+      rb0 = *(const uint4*)p;
+      rb1 = *(const uint4*)(p + 16);
+    } else {
+      rb0 = z; rb1 = z;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (it_begin < it_end) gload(it_begin);
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int it = it_begin; it < it_end; ++it) {
+    *(uint4*)(ldsA + lrow * LDS_STRIDE + lhalf * 32) = ra0;
+    *(uint4*)(ldsA + lrow * LDS_STRIDE + lhalf * 32 + 16) = ra1;
+    *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 32) = rb0;
+    *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 32 + 16) = rb1;
+    __syncthreads();
+    if (it + 1 < it_end) gload(it + 1);
+    // Each lane takes 32 contiguous bytes of its row at byte 32*fh.  The k order seen by the MFMA is a
+    // permutation of the true k, identical for A and B, so the sum over k is unchanged.
+    uint4 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* pa = ldsA + (wr * 64 + i * 32 + fr) * LDS_STRIDE + fh * 32;
+      fa[i][0] = *(const uint4*)pa;
+      fa[i][1] = *(const uint4*)(pa + 16);
+      const char* pb = ldsB + (wc * 64 + i * 32 + fr) * LDS_STRIDE + fh * 32;
+      fb[i][0] = *(const uint4*)pb;
+      fb[i][1] = *(const uint4*)(pb + 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (BF16) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fa[i][s]), __builtin_bit_cast(bf16x8, fb[j][s]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const float* a4 = (const float*)&fa[i][s];
+            const float* b4 = (const float*)&fb[j][s];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    __syncthreads();
+  }
+
+  // epilogue: C[row][col] with col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + fr;
+      if (n >= g.N) continue;
+      const float bias = g.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (l >= g.L) continue;
+        const long o = ((long)b * g.L + l) * g.N + n;
+        float v = acc[i][j][r] + bias;
+        if constexpr (RESID) v += g.resid[o];
+        if constexpr (OUT_BF16) ((bf16_t*)g.out)[o] = f32_to_bf16_bits(v);
+        else ((float*)g.out)[o] = v;
+      }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream) {
+  const int kstep = p.a_bf16 ? 32 : 16;
+  if (p.K % kstep != 0 || p.B <= 0 || p.L <= 0 || p.N <= 0 || (p.ntaps & 1) == 0) return hipErrorInvalidValue;
+  if (p.resid && p.out_bf16) return hipErrorInvalidValue;
+  dim3 grid((p.N + BN - 1) / BN, (unsigned)(p.B * ((p.L + BM - 1) / BM)));
+  dim3 block(256);
+#define ED_LAUNCH(BF, OB, RS) hipLaunchKernelGGL((gemm_generic_kernel<BF, OB, RS>), grid, block, 0, stream, p)
+  if (p.a_bf16) {
+    if (p.resid) ED_LAUNCH(true, false, true);
+    else if (p.out_bf16) ED_LAUNCH(true, true, false);
+    else ED_LAUNCH(true, false, false);
+  } else {
+    if (p.resid) ED_LAUNCH(false, false, true);
+    else if (p.out_bf16) ED_LAUNCH(false, true, false);
+    else ED_LAUNCH(false, false, false);
+  }
+#undef ED_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace ed

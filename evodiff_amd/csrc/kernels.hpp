@@ -1,0 +1,79 @@
+// Internal launcher interface between the C-ABI layer (api.hip) and the gfx950 kernels.
+// All launchers are asynchronous on `stream`, allocate nothing and never synchronise, so a
+// whole denoiser step can be captured into a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ed {
+
+typedef unsigned short bf16_t;  // storage type of a bfloat16
+
+__host__ __device__ inline bf16_t f32_to_bf16_bits(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);  // keep NaN a NaN
+  return (bf16_t)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);                // round to nearest even
+}
+
+// Device-resident per-call scalars read by kernels inside a captured graph.
+struct StepState {
+  int step;     // index of the current sampling step (advanced by advance_step_kernel)
+  int t_start;  // D3PM: t of step 0; the current t is t_start - step
+};
+
+// One implicit-GEMM problem: out[b*L + l][n] = bias[n] (+ resid) + sum_{tap,k} A[row(b, l + off(tap))][k] * W[tap][n][k]
+// with off(tap) = (tap - ntaps/2) * dilation and rows outside [0, L) contributing zero.
+struct GemmProblem {
+  const void* A;        // activations, row-major rows of K elements (fp32 or bf16)
+  long a_seq_pitch;     // rows between the starts of consecutive sequences in A
+  long a_row0;          // row of position 0 inside a sequence (halo padding in front)
+  const void* W;        // [ntaps][N][K], same element type as A
+  const float* bias;    // [N]
+  void* out;            // [B*L][N], fp32 or bf16
+  const float* resid;   // nullptr, or fp32 [B*L][N] added to the result (may alias out)
+  int B, L, N, K, ntaps, dilation;
+  bool a_bf16;          // element type of A and W
+  bool out_bf16;        // element type of out (resid != nullptr requires fp32 out)
+};
+
+// Reference-quality tile kernel: any shape with K % 32 == 0 (bf16) / K % 16 == 0 (fp32).
+hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream);
+// Tuned bf16 kernel (see gemm_bf16.hip for its shape requirements); false = shape not supported.
+bool gemm_bf16_supported(const GemmProblem& p);
+hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream);
+
+// tokens (B*L) int64 -> X fp32 [B*L][D]:  up_b + up_w @ (emb[tok] + pe[t])   (model.py:131-140)
+// tvec: int64 (B,) per-sequence timesteps with the reference's reshape quirk (row r uses tvec[r % B]),
+// or nullptr to use state->t_start - state->step for every row.  pe == nullptr: no time encoding.
+hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepState* state, const float* emb,
+                        const float* pe, int n_timesteps, const float* up_w, const float* up_b, float* X,
+                        int rows, int B, int D, int E, int n_tokens, hipStream_t stream);
+
+// out = act(LayerNorm(in)) row-wise; in fp32/bf16 [rows][C]; out fp32/bf16, row r=(b,l) stored at
+// row b*out_pitch + out_row0 + l.  act: 0 none, 1 exact GELU, 2 ReLU.
+hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
+                         const float* beta, int rows, int C, int L, long out_pitch, long out_row0, int act,
+                         hipStream_t stream);
+
+// logits[r][k] = dec_b[k] + dec_w[k] . LayerNorm(X[r])  for all rows (ByteNetLMTime.forward tail).
+hipError_t launch_final_logits(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                               const float* dec_b, float* logits, int rows, int D, int n_tokens,
+                               hipStream_t stream);
+
+// OA-DM step tail (generate.py:198-211): one categorical draw per sequence at position order[step].
+hipError_t launch_final_oadm(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                             const float* dec_b, int64_t* tokens, const int* order, const float* uniforms,
+                             const StepState* state, float* probs, int B, int L, int D, int n_draw,
+                             hipStream_t stream);
+
+// D3PM step tail (generate.py:279-298): softmax over K, fp64 posterior with Q[t] / Qbar[t-1], one draw per
+// position, in place on tokens.
+hipError_t launch_final_d3pm(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                             const float* dec_b, int64_t* tokens, const double* Q, const double* Qbar,
+                             const float* uniforms, const StepState* state, double* post, int B, int L, int D,
+                             int K, int n_timesteps, hipStream_t stream);
+
+hipError_t launch_advance_step(StepState* state, hipStream_t stream);
+
+}  // namespace ed

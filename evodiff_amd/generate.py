@@ -1,0 +1,90 @@
+"""``generate_oaardm`` / ``generate_d3pm`` with the reference's signatures, running on MI355X.
+
+Mirrors ``evodiff/generate.py:180-215`` and ``:259-302``.  The per-step work of the reference's Python
+loops (full forward, logits slice, softmax, categorical draw, token write; for D3PM the fp64 posterior
+over Q_t / Q̄_{t-1}) runs inside libevodiff_hip.so, one captured hipGraph replay per diffusion step.
+
+Randomness.  ``torch.multinomial``'s stream cannot be reproduced by any other kernel, so (north_star)
+each categorical draw is the inverse CDF of the step's probabilities at a pre-drawn uniform.  The
+position order comes from ``np.random.shuffle`` exactly as in the reference; the uniforms come from
+torch's global generator (``torch.rand``), so ``torch.manual_seed`` / ``np.random.seed`` make a run
+reproducible as they do there.  ``order=`` / ``uniforms=`` / ``start=`` (keyword-only, not in the
+reference) inject pre-drawn values for parity tests.
+"""
+import numpy as np
+import torch
+
+from .utils import Tokenizer  # noqa: F401  (re-exported like the reference module)
+
+
+def _strings(tokenizer, sample):
+    host = sample.detach().cpu().numpy()
+    return [tokenizer.untokenize(row) for row in host]
+
+
+def _inverse_cdf(p, u):
+    cdf = torch.cumsum(p, dim=-1)
+    thr = u.to(p.dtype).unsqueeze(-1) * cdf[..., -1:]
+    return (cdf <= thr).sum(dim=-1).clamp(max=p.shape[-1] - 1)
+
+
+def generate_oaardm(model, tokenizer, seq_len, penalty=None, batch_size=3, device='cuda', *, order=None,
+                    uniforms=None, start=None):
+    all_aas = tokenizer.all_aas
+    mask = tokenizer.mask_id
+    n_draw = len(all_aas) - 6                      # generate.py:198: never predict non-standard AAs
+
+    if start is None:
+        sample = torch.full((batch_size, seq_len), mask, dtype=torch.long, device=device)
+    else:
+        sample = start.to(device=device, dtype=torch.long).clone().contiguous()
+
+    if order is None:                              # unmask one location at a time, in random order
+        loc = np.arange(seq_len)
+        np.random.shuffle(loc)
+    else:
+        loc = np.asarray(order)
+    n_steps = len(loc)
+    draws = 1 if penalty is None else 2
+    if uniforms is None:
+        uniforms = torch.rand((n_steps * draws, batch_size), dtype=torch.float32, device=device)
+    uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device)
+
+    with torch.no_grad():
+        if penalty is None:
+            model.oadm_sample(sample, torch.as_tensor(loc, dtype=torch.int32), uniforms[:n_steps], n_draw)
+        else:
+            # repetition penalty (generate.py:202-210): re-draw when the new token repeats a neighbour.
+            # Rare path: the forward runs on the GPU, the per-sequence re-draw logic stays on the host side.
+            timestep = torch.zeros(batch_size, dtype=torch.long, device=device)
+            for s, i in enumerate(int(v) for v in loc):
+                p = torch.softmax(model(sample, timestep)[:, i, :n_draw], dim=1)
+                p_sample = _inverse_cdf(p, uniforms[s])
+                left = sample[:, i - 1] if i > 0 else torch.full_like(p_sample, -1)
+                right = sample[:, i + 1] if i < seq_len - 1 else torch.full_like(p_sample, -1)
+                repeat = (left == p_sample) | (right == p_sample)
+                if bool(repeat.any()):
+                    p2 = p.clone()
+                    rows = torch.nonzero(repeat).squeeze(1)
+                    p2[rows, p_sample[rows]] /= penalty
+                    p_sample = torch.where(repeat, _inverse_cdf(p2, uniforms[n_steps + s]), p_sample)
+                sample[:, i] = p_sample
+    untokenized = _strings(tokenizer, sample)
+    return sample, untokenized
+
+
+def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, batch_size=3, device='cuda', *, uniforms=None,
+                  start=None):
+    """Start from uniformly random tokens and run the reverse chain t = timesteps-1 ... 1."""
+    if start is None:
+        sample = torch.randint(0, tokenizer.K, (batch_size, seq_len))
+    else:
+        sample = torch.as_tensor(start)
+    sample = sample.to(torch.long).to(device).contiguous()
+    if uniforms is None:
+        uniforms = torch.rand((timesteps, batch_size, seq_len), dtype=torch.float32, device=device)
+    with torch.no_grad():
+        model.d3pm_sample(sample, Q, Q_bar, torch.as_tensor(uniforms), tokenizer.K, t_start=timesteps - 1)
+    untokenized = _strings(tokenizer, sample)
+    print("final seq", untokenized)
+    return sample, untokenized

@@ -1,0 +1,97 @@
+"""Sequence-model loaders with the reference's names, signatures and return tuples.
+
+Mirrors ``evodiff/pretrained.py``: ``load_sequence_checkpoint`` (:14-54), ``D3PM_BLOSUM_{640M,38M}``
+(:81-110), ``D3PM_UNIFORM_{640M,38M}`` (:112-140), ``OA_DM_{640M,38M}`` (:143-161).  Differences, all
+additive: checkpoints are never downloaded (no network) — pass ``path_to_checkpoints`` or set
+``$EVODIFF_CHECKPOINT_DIR``; ``random_init=True`` keeps the constructor's default initialisation
+(synthetic weights for benchmarks and parity tests).  The returned model is an
+``evodiff_amd.model.ByteNetLMTime`` whose forward runs in libevodiff_hip.so.
+"""
+import json
+import os
+
+import torch
+
+from .collaters import D3PMCollater, OAMaskCollater
+from .constants import MSA_ALPHABET
+from .model import ByteNetLMTime
+from .utils import DEFAULT_BLOSUM, Tokenizer, download_model
+
+_CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
+_CHECKPOINT_STEMS = ("oaar", "d3pm-blosum", "d3pm-uniform")
+
+
+def _config_path(name):
+    return os.path.join(_CONFIG_DIR, name)
+
+
+def load_sequence_checkpoint(model_name, config_path, diffusion_timesteps, tokenizer=Tokenizer(), causal=False,
+                             n_tokens=len(MSA_ALPHABET), path_to_checkpoints=None, random_init=False):
+    with open(config_path, "r") as f:
+        config = json.load(f)
+    model = ByteNetLMTime(n_tokens, config["d_embed"], config["d_model"], config["n_layers"], config["kernel_size"],
+                          config["r"], causal=causal, padding_idx=tokenizer.mask_id, rank=config.get("rank"),
+                          dropout=0.0, tie_weights=False, final_ln=True, slim=config.get("slim", True),
+                          activation=config.get("activation", "relu"), timesteps=diffusion_timesteps)
+    if random_init:
+        return model, tokenizer
+    if path_to_checkpoints is not None:
+        state_dict = torch.load(path_to_checkpoints, map_location=torch.device("cpu"), weights_only=True)
+    else:
+        state_dict = download_model(model_name)
+    msd = state_dict["model_state_dict"]
+    # checkpoints were saved from DistributedDataParallel: strip the "module." prefix (pretrained.py:47-51)
+    msd = {(k.split("module.")[1] if k.startswith("module.") else k): v for k, v in msd.items()}
+    model.load_state_dict(msd)
+    return model, tokenizer
+
+
+def _d3pm(model_name, config, blosum, return_all, path_to_checkpoints, random_init):
+    dt = 500
+    if blosum:
+        tokenizer = Tokenizer(path_to_blosum=DEFAULT_BLOSUM, sequences=True)
+        Q_prod, Q_t = tokenizer.q_blosum_schedule(timesteps=dt)
+    else:
+        tokenizer = Tokenizer(sequences=True)
+        Q_prod, Q_t = tokenizer.q_random_schedule(timesteps=dt)
+    collater = D3PMCollater(tokenizer=tokenizer, num_timesteps=dt, Q=Q_t, Q_bar=Q_prod)
+    model, tokenizer = load_sequence_checkpoint(model_name, _config_path(config), diffusion_timesteps=dt,
+                                                tokenizer=tokenizer, path_to_checkpoints=path_to_checkpoints,
+                                                random_init=random_init)
+    scheme = "d3pm"
+    if return_all:
+        return model, collater, tokenizer, scheme, dt, Q_prod, Q_t
+    return model, collater, tokenizer, scheme
+
+
+def D3PM_BLOSUM_640M(return_all=False, path_to_checkpoints=None, random_init=False):
+    return _d3pm("d3pm-blosum-640M", "config640M.json", True, return_all, path_to_checkpoints, random_init)
+
+
+def D3PM_BLOSUM_38M(return_all=False, path_to_checkpoints=None, random_init=False):
+    return _d3pm("d3pm-blosum-38M", "config38M.json", True, return_all, path_to_checkpoints, random_init)
+
+
+def D3PM_UNIFORM_640M(return_all=False, path_to_checkpoints=None, random_init=False):
+    return _d3pm("d3pm-uniform-640M", "config640M.json", False, return_all, path_to_checkpoints, random_init)
+
+
+def D3PM_UNIFORM_38M(return_all=False, path_to_checkpoints=None, random_init=False):
+    return _d3pm("d3pm-uniform-38M", "config38M.json", False, return_all, path_to_checkpoints, random_init)
+
+
+def _oadm(model_name, config, path_to_checkpoints, random_init):
+    tokenizer = Tokenizer()
+    collater = OAMaskCollater(tokenizer=tokenizer)
+    model, tokenizer = load_sequence_checkpoint(model_name, _config_path(config), diffusion_timesteps=None,
+                                                tokenizer=tokenizer, n_tokens=len(MSA_ALPHABET),
+                                                path_to_checkpoints=path_to_checkpoints, random_init=random_init)
+    return model, collater, tokenizer, "mask"
+
+
+def OA_DM_640M(path_to_checkpoints=None, random_init=False):
+    return _oadm("oaar-640M", "config640M.json", path_to_checkpoints, random_init)
+
+
+def OA_DM_38M(path_to_checkpoints=None, random_init=False):
+    return _oadm("oaar-38M", "config38M.json", path_to_checkpoints, random_init)

@@ -1,0 +1,129 @@
+/*
+ * evodiff_hip.h — C ABI of libevodiff_hip.so: the MI355X (gfx950) implementation of EvoDiff's
+ * ByteNetLMTime denoiser forward and per-step samplers.
+ *
+ * The reference (microsoft/evodiff) has no FFI: this path sits behind plain Python
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces; the
+ * ctypes binding a maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative ED_E* code on failure; the message for
+ *     the calling thread's last failure is returned by ed_last_error().
+ *   - Pointers named *_dev are device (HBM) pointers on the model's device; *_host are host
+ *     pointers.  Buffers are owned by the caller; the model owns its packed weights, workspace
+ *     and captured graphs.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous
+ *     with respect to the host unless stated otherwise.
+ *   - One model handle serves one device; a handle is not thread-safe (the reference is
+ *     single-threaded on this path as well).
+ *   - No CPU fallback exists anywhere in this library.
+ */
+#ifndef EVODIFF_HIP_H
+#define EVODIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ED_ABI_VERSION 1
+
+enum {
+  ED_OK = 0,
+  ED_EINVAL = -1,     /* bad argument / shape */
+  ED_ESTATE = -2,     /* call order (e.g. forward before commit, missing tensor) */
+  ED_EHIP = -3,       /* a HIP runtime call failed */
+  ED_ENOMEM = -4
+};
+
+enum { ED_PREC_FP32 = 0, ED_PREC_BF16 = 1 };
+
+/* Hyper-parameters of ByteNetLMTime as constructed by evodiff/pretrained.py:39-42 from
+ * config/config{38M,640M}.json (n_tokens=31, final_ln=True, tie_weights=False, causal=False). */
+typedef struct ed_config {
+  int32_t n_tokens;     /* len(MSA_ALPHABET) = 31 */
+  int32_t d_embed;      /* 8 */
+  int32_t d_model;      /* 1024 / 1280 */
+  int32_t d_hidden;     /* d_model/2 if slim else d_model (evodiff/model.py:110-112) */
+  int32_t n_layers;     /* 16 / 56 */
+  int32_t kernel_size;  /* 5 */
+  int32_t r;            /* 128: dilation of layer n is 2**(n % (log2(r)+1)) (model.py:108-109) */
+  int32_t timesteps;    /* 0 = no timestep encoding (OA-DM); 500 for D3PM (model.py:93-94,133) */
+  int32_t activation;   /* 1 = exact-erf GELU (the only activation on this path), 0 = ReLU */
+} ed_config;
+
+typedef struct ed_model ed_model;
+
+/* Per-kernel-class probe record (see ed_probe_*): device time by HIP events around launches. */
+enum { ED_K_EMBED = 0, ED_K_LNACT = 1, ED_K_GEMM1X1 = 2, ED_K_CONV = 3, ED_K_FINAL = 4, ED_K_COUNT = 5 };
+typedef struct ed_probe_stat {
+  double ms;          /* summed device time of the probed launches */
+  double flops;       /* summed algorithmic FLOPs (in-range taps only) of those launches */
+  double bytes;       /* summed algorithmic HBM bytes (operands read once, results written once) */
+  int64_t launches;
+} ed_probe_stat;
+
+int ed_abi_version(void);
+const char* ed_last_error(void);
+
+/* Replaces: ByteNetLMTime.__init__ (evodiff/model.py:152-168).  Selects `device`. */
+int ed_model_create(const ed_config* cfg, int device, ed_model** out);
+void ed_model_destroy(ed_model* m);
+
+/* Replaces: nn.Module.load_state_dict as used by load_sequence_checkpoint
+ * (evodiff/pretrained.py:47-52).  `key` is a reference state_dict key without the "module."
+ * prefix, e.g. "embedder.layers.3.conv.weight"; `host` is contiguous fp32 in
+ * the PyTorch layout; `numel` must match.  The extra key "time_encoding.table" (timesteps x
+ * d_embed) carries the sin/cos table of PositionalEncoding1D (model.py:29-33), which the
+ * reference rebuilds on every call. */
+int ed_model_load_tensor(ed_model* m, const char* key, const float* host, int64_t numel);
+/* Checks that every tensor is present and packs the device weights (fp32 and bf16 images). */
+int ed_model_commit(ed_model* m);
+/* Number of parameters packed (for cross-checks against 37,890,327 / 642,951,959). */
+int64_t ed_model_num_params(const ed_model* m);
+
+/* Replaces: ByteNetLMTime.forward(x, y, input_mask=None) (evodiff/model.py:170-173).
+ * tokens_dev int64 (B, L); timesteps_dev int64 (B,) (ignored when cfg.timesteps == 0);
+ * logits_dev fp32 (B, L, n_tokens). */
+int ed_forward(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
+               float* logits_dev, int precision, void* stream);
+/* Debug/validation variant: additionally copies the residual stream after the embedding and after
+ * every block into acts_dev, fp32 (n_layers + 1, B, L, d_model). */
+int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
+                       float* logits_dev, float* acts_dev, int precision, void* stream);
+
+/* Replaces: the loop of generate_oaardm (evodiff/generate.py:193-211, penalty=None).
+ * tokens_dev int64 (B, L), in/out (the caller fills it with mask_id for unconditional sampling);
+ * order_dev int32 (n_steps,) = positions to fill (np.random.shuffle'd arange in the reference);
+ * uniforms_dev fp32 (n_steps, B) in [0,1): the categorical draw at step s, sequence b is the
+ * inverse CDF of softmax(logits[b, order[s], :n_draw]) at uniforms[s, b] (torch.multinomial in
+ * the reference; north_star fixes pre-drawn uniforms on both sides).  n_draw = 21 in the
+ * reference (generate.py:198).  probs_dev: optional fp32 (n_steps, B, n_draw) receiving the
+ * softmax rows (NULL to skip).  use_graph != 0 replays one captured hipGraph per step. */
+int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, const float* uniforms_dev,
+                   int B, int L, int n_steps, int n_draw, float* probs_dev, int precision, int use_graph,
+                   void* stream);
+
+/* Replaces: the loop of generate_d3pm (evodiff/generate.py:274-298).
+ * tokens_dev int64 (B, L) in/out = x_t on entry; Q_dev / Qbar_dev fp64 (timesteps, K, K) as returned by
+ * Tokenizer.q_blosum_schedule / q_random_schedule (evodiff/utils.py:216-249); runs n_steps steps
+ * t = t_start, t_start-1, ... (the reference runs t = timesteps-1 ... 1).  uniforms_dev fp32
+ * (timesteps, B, L): the step at time t consumes row timesteps-1-t; at t == 1 the reference's second,
+ * restricted draw over the first K-6 categories (generate.py:293-294) consumes row timesteps-1.
+ * post_dev: optional fp64 (n_steps, B, L, K) receiving the normalised posterior (NULL to skip). */
+int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const double* Qbar_dev,
+                   const float* uniforms_dev, int B, int L, int K, int t_start, int n_steps,
+                   double* post_dev, int precision, int use_graph, void* stream);
+
+/* Measurement hooks (no counterpart in the reference).  With a probe interval n > 0, every n-th
+ * sampling step (and every ed_forward) runs eagerly with a HIP-event pair around each kernel
+ * launch on the caller's stream; ed_probe_read synchronises the stream, accumulates the event
+ * times into stats[ED_K_COUNT] and clears the pending events. */
+int ed_probe_config(ed_model* m, int every_n_steps);
+int ed_probe_read(ed_model* m, ed_probe_stat* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVODIFF_HIP_H */

@@ -1,0 +1,278 @@
+"""GPU parity: libevodiff_hip.so (through the C ABI, via evodiff_amd) against the CPU oracle and the golden
+fixtures.  Run on an MI355X with ``pytest -m gpu``.
+
+Tolerances (north_star): fp32 validation path — per-step logits within 1e-4 relative (max |Δ| over the
+tensor divided by max |ref|); bf16 fast path — within BF16_TOL stated below; sampled tokens bit-exact
+wherever the oracle's draw is not within DRAW_MARGIN of a category boundary.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bytenet_ref as R
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+BF16_TOL = 3e-2          # relative to max |logit|; bf16 operands (8-bit mantissa) through up to 56 residual blocks
+DRAW_MARGIN_FP32 = 1e-4  # probability mass; draws closer than this to a CDF boundary may differ
+DRAW_MARGIN_BF16 = 1e-2
+
+TINY = dict(d_embed=8, d_model=64, n_layers=8, kernel_size=5, r=128, slim=True, activation="gelu")
+TINY_WIDE = dict(d_embed=8, d_model=256, n_layers=9, kernel_size=5, r=128, slim=False, activation="gelu")
+MID = dict(d_embed=8, d_model=384, n_layers=10, kernel_size=5, r=128, slim=True, activation="gelu")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def product_model(oracle_model, cfg, timesteps=None, precision="fp32"):
+    from evodiff_amd.model import ByteNetLMTime
+    m = ByteNetLMTime(len(R.MSA_ALPHABET), cfg["d_embed"], cfg["d_model"], cfg["n_layers"], cfg["kernel_size"],
+                      cfg["r"], causal=False, padding_idx=R.MASK_ID, rank=None, dropout=0.0, tie_weights=False,
+                      final_ln=True, slim=cfg["slim"], activation=cfg["activation"], timesteps=timesteps)
+    m.load_state_dict(oracle_model.state_dict())
+    m.precision = precision
+    return m.eval()
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def test_library_loaded_is_the_in_tree_hip_build():
+    from evodiff_amd import _lib
+    lib = _lib.load()
+    assert lib.ed_abi_version() == 1
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(os.path.dirname(os.path.dirname(__file__)), "evodiff_amd",
+                                                        "csrc", "libevodiff_hip.so"))
+
+
+def test_tiny_forward_against_reference_golden(golden_dir, dev):
+    """Weights, inputs and outputs all come from the reference's own model.py (fixture)."""
+    g = np.load(os.path.join(golden_dir, "tiny_forward.npz"))
+    oracle = R.build_model(TINY, None, 11)
+    oracle.load_state_dict({k: torch.from_numpy(g["sd/" + k]) for k in oracle.state_dict().keys()})
+    m = product_model(oracle, TINY, precision="fp32")
+    for L in (7, 100, 300):
+        x = torch.from_numpy(g[f"x_L{L}"]).to(dev)
+        logits, acts = m(x, torch.zeros(2, dtype=torch.long, device=dev), return_blocks=True)
+        assert rel_err(logits.cpu().numpy(), g[f"logits_L{L}"]) < FP32_TOL
+        if g[f"blocks_L{L}"].size:
+            ref = g[f"blocks_L{L}"]
+            for i in range(ref.shape[0]):
+                assert rel_err(acts[i].cpu().numpy(), ref[i]) < FP32_TOL, f"block {i}"
+    m.precision = "bf16"
+    x = torch.from_numpy(g["x_L100"]).to(dev)
+    assert rel_err(m(x, torch.zeros(2, dtype=torch.long, device=dev)).cpu().numpy(), g["logits_L100"]) < BF16_TOL
+
+
+def test_time_encoding_quirk_against_reference_golden(golden_dir, dev):
+    g = np.load(os.path.join(golden_dir, "tiny_timeenc.npz"))
+    oracle = R.build_model(TINY, 500, 13)
+    m = product_model(oracle, TINY, timesteps=500, precision="fp32")
+    x, y = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    logits, acts = m(x, y, return_blocks=True)
+    assert rel_err(acts[0].cpu().numpy(), g["embed"]) < 1e-6
+    assert rel_err(logits.cpu().numpy(), g["logits"]) < FP32_TOL
+
+
+@pytest.mark.parametrize("cfg,B,L", [(MID, 3, 1), (MID, 3, 37), (MID, 2, 128), (MID, 2, 300), (TINY_WIDE, 1, 513),
+                                     (TINY_WIDE, 5, 256)])
+def test_forward_vs_oracle_shapes(dev, cfg, B, L):
+    """Ragged and edge lengths: L=1, L below/at/above the 128-row tile, L > 2*max dilation."""
+    oracle = R.build_model(cfg, None, 21)
+    m = product_model(oracle, cfg)
+    x = torch.from_numpy(np.random.default_rng(B * 1000 + L).integers(0, 31, (B, L)))
+    with torch.no_grad():
+        ref = oracle(x, torch.zeros(B, dtype=torch.long)).numpy()
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    assert rel_err(m(x.to(dev), t).cpu().numpy(), ref) < FP32_TOL
+    m.precision = "bf16"
+    assert rel_err(m(x.to(dev), t).cpu().numpy(), ref) < BF16_TOL
+
+
+def test_38m_forward_vs_oracle_and_golden(golden_dir, dev):
+    cfg = R.MODEL_CONFIGS["38M"]
+    g = np.load(os.path.join(golden_dir, "m38_forward.npz"))
+    oracle = R.build_model(cfg, None, 0)
+    m = product_model(oracle, cfg)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        ref = oracle(x, torch.zeros(2, dtype=torch.long)).numpy()
+    t = torch.zeros(2, dtype=torch.long, device=dev)
+    got = m(x.to(dev), t).cpu().numpy()
+    assert rel_err(got, ref) < FP32_TOL
+    # the fixture was produced by the reference constructor under the same seed; if this host's RNG
+    # stream matches (same torch build), the GPU logits must also match the reference's file
+    if np.abs(ref - g["logits"]).max() < 1e-5:
+        assert rel_err(got, g["logits"]) < FP32_TOL
+    m.precision = "bf16"
+    assert rel_err(m(x.to(dev), t).cpu().numpy(), ref) < BF16_TOL
+
+
+def _check_draws(got_tokens, ref_tokens, margins, margin_tol):
+    got_tokens, ref_tokens, margins = map(np.asarray, (got_tokens, ref_tokens, margins))
+    safe = margins > margin_tol
+    assert np.array_equal(got_tokens[safe], ref_tokens[safe])
+    return int(safe.sum())
+
+
+@pytest.mark.parametrize("precision,tol,margin", [("fp32", FP32_TOL, DRAW_MARGIN_FP32), ("bf16", BF16_TOL, DRAW_MARGIN_BF16)])
+def test_oadm_steps_teacher_forced(golden_dir, dev, precision, tol, margin):
+    """Every step of the reference's generate_oaardm trace (fixture), restarted from the oracle's state."""
+    g = np.load(os.path.join(golden_dir, "oadm_trace.npz"))
+    oracle = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    m = product_model(oracle, TINY_WIDE, precision=precision)
+    order, uni = g["order"], torch.from_numpy(g["uniforms"])
+    B, L = 2, len(order)
+    trace = []
+    R.generate_oaardm_ref(oracle, L, B, order, uni, trace=trace)
+    state = torch.full((B, L), R.MASK_ID, dtype=torch.long)
+    n_safe = 0
+    for s, tr in enumerate(trace):
+        sample = state.clone().to(dev)
+        probs = m.oadm_sample(sample, torch.tensor([order[s]]), uni[s:s + 1].to(dev), R.OADM_DRAW, return_probs=True)
+        assert np.abs(probs[0].cpu().numpy() - g["p"][s]).max() < (1e-5 if precision == "fp32" else 2e-2)
+        n_safe += _check_draws(sample[:, order[s]].cpu().numpy(), g["tok"][s], g["margin"][s], margin)
+        others = np.ones(L, bool)
+        others[order[s]] = False
+        assert np.array_equal(sample.cpu().numpy()[:, others], state.numpy()[:, others])   # only column pos changes
+        state = tr["sample"]
+    assert n_safe > 0.5 * B * L, "test is vacuous: most draws sit on a category boundary"
+
+
+def test_oadm_full_trajectory_fp32(golden_dir, dev):
+    """Free-running L-step loop (hipGraph replay) reproduces the reference's final sequences in fp32."""
+    from evodiff_amd.generate import generate_oaardm
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(golden_dir, "oadm_trace.npz"))
+    assert g["margin"].min() > DRAW_MARGIN_FP32, "fixture has a boundary-ambiguous draw; regenerate with another seed"
+    oracle = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    m = product_model(oracle, TINY_WIDE, precision="fp32")
+    for use_graph in (True, False):
+        m.use_graph = use_graph
+        sample, strings = generate_oaardm(m, Tokenizer(), len(g["order"]), batch_size=2, device=dev,
+                                          order=g["order"], uniforms=g["uniforms"])
+        assert np.array_equal(sample.cpu().numpy(), g["final"])
+        assert strings == [str(s) for s in g["strings"]]
+
+
+@pytest.mark.parametrize("tag", ["blosum", "uniform"])
+def test_d3pm_against_reference_trace(golden_dir, dev, tag):
+    from evodiff_amd.utils import DEFAULT_BLOSUM, Tokenizer
+    g = np.load(os.path.join(golden_dir, f"d3pm_trace_{tag}.npz"))
+    oracle = R.build_model(TINY, 500, 13)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    m = product_model(oracle, TINY, timesteps=500, precision="fp32")
+    if tag == "blosum":
+        tok = Tokenizer(path_to_blosum=DEFAULT_BLOSUM, sequences=True)
+        Qbar, Q = tok.q_blosum_schedule(timesteps=500)
+    else:
+        tok = Tokenizer(sequences=True)
+        Qbar, Q = tok.q_random_schedule(timesteps=500)
+    uni = torch.from_numpy(g["uniforms"])
+    trace = []
+    R.generate_d3pm_ref(oracle, Q, Qbar, 500, torch.from_numpy(g["start"]), uni, K=tok.K, trace=trace)
+    # teacher-forced single steps incl. t == 1 (restricted draw), with the posterior checked in fp64
+    states = [torch.from_numpy(g["start"])] + [t["sample"] for t in trace]
+    for s in (0, 1, 2, 250, 497, 498):
+        t = 499 - s
+        sample = states[s].clone().to(dev)
+        post = m.d3pm_sample(sample, Q, Qbar, uni, tok.K, t_start=t, n_steps=1, return_post=True)
+        ref_post = trace[s]["post"].numpy()
+        assert np.abs(post[0].cpu().numpy() - ref_post).max() < 2e-5
+        _check_draws(sample.cpu().numpy(), trace[s]["sample"].numpy(), trace[s]["margin"].numpy(), DRAW_MARGIN_FP32)
+    # free-running 499 steps (hipGraph replay): chaotic, so only require agreement while no ambiguous draw occurred
+    from evodiff_amd.generate import generate_d3pm
+    sample, strings = generate_d3pm(m, tok, Q, Qbar, 500, 20, batch_size=2, device=dev, uniforms=uni,
+                                    start=torch.from_numpy(g["start"]))
+    if min(float(t["margin"].min()) for t in trace) > DRAW_MARGIN_FP32:
+        assert np.array_equal(sample.cpu().numpy(), g["final"])
+    assert sample.max() < tok.K - 6          # final step only emits canonical amino acids
+
+
+def test_graph_replay_equals_eager_bf16(dev):
+    oracle = R.build_model(MID, None, 5)
+    m = product_model(oracle, MID, precision="bf16")
+    B, L = 4, 96
+    order = torch.from_numpy(np.random.default_rng(0).permutation(L).astype(np.int32))
+    uni = torch.from_numpy(np.random.default_rng(1).random((L, B), dtype=np.float32)).to(dev)
+    outs = []
+    for use_graph in (True, False, True):
+        m.use_graph = use_graph
+        sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+        m.oadm_sample(sample, order, uni, R.OADM_DRAW)
+        outs.append(sample.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert (outs[0] < R.OADM_DRAW).all()
+
+
+def test_640m_steps_vs_oracle(dev):
+    """OA_DM_640M geometry (config 2 at reduced batch): 8 teacher-forced steps, fp32 1e-4 and bf16."""
+    cfg = R.MODEL_CONFIGS["640M"]
+    oracle = R.build_model(cfg, None, 0)
+    m = product_model(oracle, cfg, precision="fp32")
+    B, L, n = 2, 256, 8
+    rng = np.random.default_rng(0)
+    order = rng.permutation(L)[:n]
+    uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32))
+    state = torch.full((B, L), R.MASK_ID, dtype=torch.long)
+    state[:, rng.permutation(L)[: L // 2]] = torch.from_numpy(rng.integers(0, 20, (B, L // 2)))
+    zeros = torch.zeros(B, dtype=torch.long, device=dev)
+    for s in range(n):
+        nxt, logits, p, margin = R.oadm_step(oracle, state, int(order[s]), uni[s])
+        for precision, tol, mtol in (("fp32", FP32_TOL, DRAW_MARGIN_FP32), ("bf16", BF16_TOL, DRAW_MARGIN_BF16)):
+            m.precision = precision
+            if s in (0, n - 1):
+                assert rel_err(m(state.to(dev), zeros).cpu().numpy(), logits.numpy()) < tol
+            sample = state.clone().to(dev)
+            m.oadm_sample(sample, torch.tensor([order[s]]), uni[s:s + 1].to(dev), R.OADM_DRAW)
+            safe = margin.numpy() > mtol
+            assert np.array_equal(sample[:, order[s]].cpu().numpy()[safe], nxt[:, order[s]].numpy()[safe])
+        state = nxt
+
+
+def test_full_size_batch_invariance_640m(dev):
+    """BASELINE config 2 (B=64, L=256, 640M, bf16): sequences are independent, so rows of a 64-batch run
+    must equal the same rows sampled in a batch of 2 (which test_640m_steps_vs_oracle ties to the oracle)."""
+    from evodiff_amd.pretrained import OA_DM_640M
+    torch.manual_seed(0)
+    m, _, tok, _ = OA_DM_640M(random_init=True)
+    m.precision = "bf16"
+    B, L, n = 64, 256, 4
+    order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
+    uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32)).to(dev)
+    big = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
+    pb = m.oadm_sample(big, order, uni, R.OADM_DRAW, return_probs=True)
+    small = torch.full((2, L), tok.mask_id, dtype=torch.long, device=dev)
+    ps = m.oadm_sample(small, order, uni[:, 62:64].contiguous(), R.OADM_DRAW, return_probs=True)
+    assert torch.equal(big[62:64], small)
+    assert torch.equal(pb[:, 62:64], ps)
+    assert int((big != tok.mask_id).sum()) == B * n
+
+
+def test_errors_are_raised_not_faults(dev):
+    from evodiff_amd import _lib
+    oracle = R.build_model(TINY, None, 1)
+    m = product_model(oracle, TINY)
+    with pytest.raises(_lib.EvoDiffHipError):
+        m(torch.zeros((1, 4), dtype=torch.long), torch.zeros(1, dtype=torch.long))          # CPU tensors
+    with pytest.raises(IndexError):
+        m(torch.full((1, 4), 31, dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.long, device=dev))
+    sample = torch.full((2, 8), R.MASK_ID, dtype=torch.long, device=dev)
+    with pytest.raises(_lib.EvoDiffHipError):
+        m.oadm_sample(sample, torch.tensor([8]), torch.zeros((1, 2), device=dev), R.OADM_DRAW)   # position out of range
+    with pytest.raises((ValueError, _lib.EvoDiffHipError)):
+        m.d3pm_sample(sample, torch.zeros(1), torch.zeros(1), torch.zeros(1), 26)               # no timesteps
