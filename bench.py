@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path on MI355X: OA_DM_640M unconditional sampling, length 256 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over one batch: ``generate_oaardm``'s loop for B=64 sequences of
+L=256 (256 denoiser forwards + draws) on every rank, followed by the all-gather of the finished sequences when
+N > 1.  Weights are synthetic (reference-constructor default init under seed 0), inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel is the dilated-conv implicit GEMM.  Its launches are timed live with HIP-event
+pairs on the launch stream on every 32nd diffusion step inside the timed region; achieved = algorithmic FLOPs
+of those launches (in-range taps only) / their summed duration, against the 2.5 PFLOP/s dense
+bf16 MFMA peak.  cpu_baseline: the CPU oracle (a port of the reference's PyTorch path) timed on this host for
+a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_FP32_TFLOPS = 157.3
+
+
+def cpu_baseline(L, seconds_budget=20.0):
+    """The CPU oracle on the same model and length, B=1, for a bounded number of diffusion steps."""
+    from oracle import bytenet_ref as R
+    threads = torch.get_num_threads()
+    model = R.build_model(R.MODEL_CONFIGS["640M"], None, 0)
+    rng = np.random.default_rng(0)
+    order = rng.permutation(L)
+    uni = torch.from_numpy(rng.random((L, 1), dtype=np.float32))
+    sample = torch.full((1, L), R.MASK_ID, dtype=torch.long)
+    sample, *_ = R.oadm_step(model, sample, int(order[0]), uni[0])          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 8 or (time.perf_counter() - t0 < seconds_budget and n < L - 1):
+        sample, *_ = R.oadm_step(model, sample, int(order[n + 1]), uni[n + 1])
+        n += 1
+    per_step = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / (per_step * L), "unit": "sequences/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (fp32 PyTorch CPU) OA_DM_640M B=1 L={L}: {n} diffusion steps timed, "
+                      f"{per_step:.3f} s/step, extrapolated to {L} steps per sequence"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--model", default="640M", choices=["640M", "38M"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-every", type=int, default=32)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from evodiff_amd import pretrained
+    torch.manual_seed(0)                      # same synthetic weights on every rank
+    loader = pretrained.OA_DM_640M if args.model == "640M" else pretrained.OA_DM_38M
+    model, _, tokenizer, _ = loader(random_init=True)
+    model.precision = args.precision
+    model.use_graph = not args.no_graph
+    B, L = args.batch, args.seq_len
+    n_draw = len(tokenizer.all_aas) - 6
+
+    total = args.warmup + args.steps
+    # independent sequences: each rank samples its own shard with its own order/uniform streams
+    rng = np.random.default_rng(1000 + rank)
+    orders = [torch.from_numpy(rng.permutation(L).astype(np.int32)).to(dev) for _ in range(total)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2000 + rank)
+    uniforms = [torch.rand((L, B), generator=gen, device=dev, dtype=torch.float32) for _ in range(total)]
+    samples = [torch.full((B, L), tokenizer.mask_id, dtype=torch.long, device=dev) for _ in range(total)]
+    gathered = torch.empty((world * B, L), dtype=torch.long, device=dev) if world > 1 else None
+
+    def one_step(i):
+        model.oadm_sample(samples[i], orders[i], uniforms[i], n_draw)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, samples[i])      # RCCL over xGMI: the finished sequences
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    model.hip_handle(dev)                      # weight packing / upload: outside the timed region
+    for i in range(args.warmup):
+        one_step(i)                            # includes graph capture
+    model.probe(args.probe_every)
+    if args.warmup:
+        model.probe_read()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = model.probe_read()
+    model.probe(0)
+    done = samples[-1]
+    assert int((done == tokenizer.mask_id).sum()) == 0 and int(done.max()) < n_draw, "sampling left masks behind"
+
+    if rank == 0:
+        conv = stats["conv"]
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        out = {
+            "metric": "sequences/sec, OA_DM_640M len-256 sampling",
+            "value": world * B * args.steps / elapsed,
+            "unit": "sequences/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"OA_DM_{args.model} unconditional generate_oaardm, batch {B} per GPU, "
+                                   f"seq_len {L} ({L} diffusion steps per batch), hipGraph replay "
+                                   f"{'off' if args.no_graph else 'on'}",
+                       "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world} (sequence sharding)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "dilated-conv implicit GEMM", "launches_timed": conv["launches"],
+                         "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
+                         "flops_per_launch": conv["flops"] / max(conv["launches"], 1)},
+            "kernel_ms_share": {k: v["ms"] for k, v in stats.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
