@@ -92,7 +92,8 @@ struct ed_model {
 
   // workspace
   int ws_B = 0, ws_L = 0;
-  DevBuf X, Abuf, Ybuf, state, tok, order, uni, qbuf, tvec;
+  DevBuf X, Abuf, Ybuf, Cpad, state, tok, order, uni, qbuf, tvec;
+  long conv_pitch = 0, conv_row0 = 0;  // layout of Cpad: [B][conv_pitch][d_hidden], position 0 at row conv_row0
   hipStream_t cap_stream = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
 
@@ -218,10 +219,10 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
 }
 
 int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, const float* g, const float* b,
-           int rows, int C, int L, int act, hipStream_t s) {
+           int rows, int C, int L, long out_pitch, long out_row0, int act, hipStream_t s) {
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
-  LAUNCH_TRY(launch_ln_act(in, in_bf16, out, out_bf16, g, b, rows, C, L, L, 0, act, s));
+  LAUNCH_TRY(launch_ln_act(in, in_bf16, out, out_bf16, g, b, rows, C, L, out_pitch, out_row0, act, s));
   LAUNCH_TRY(pr.end(ED_K_LNACT, 0.0, (double)rows * C * ((in_bf16 ? 2.0 : 4.0) + (out_bf16 ? 2.0 : 4.0))));
   return ED_OK;
 }
@@ -241,6 +242,21 @@ int ensure_workspace(ed_model* m, int B, int L) {
   HIP_TRY(need(m->tok, (size_t)B * L * 8));
   HIP_TRY(need(m->tvec, (size_t)B * 8));
   HIP_TRY(need(m->state, 256));
+  // Convolution input: per sequence [halo zeros | L rows (+ round-up to the 256-row tile) | halo zeros]; the
+  // LayerNorm that produces it only ever writes the L valid rows, so the zeros survive across steps.
+  int max_dil = 1;
+  for (const auto& lw : m->layers) max_dil = std::max(max_dil, lw.dilation);
+  const long halo = (long)(c.kernel_size / 2) * max_dil;
+  const long pitch = halo + ((L + 255) / 256) * 256L + halo;
+  const size_t cbytes = (size_t)B * pitch * c.d_hidden * 4;
+  const bool relayout = B != m->ws_B || L != m->ws_L || pitch != m->conv_pitch || cbytes > m->Cpad.bytes;
+  HIP_TRY(need(m->Cpad, cbytes));
+  if (relayout) {
+    HIP_TRY(hipMemset(m->Cpad.p, 0, m->Cpad.bytes));
+    grew = true;  // the graphs bake the pitch in
+  }
+  m->conv_pitch = pitch;
+  m->conv_row0 = halo;
   if (grew) m->drop_graphs();  // captured graphs hold the old pointers
   m->ws_B = B;
   m->ws_L = L;
@@ -256,19 +272,21 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, hipStream_t s) 
   float* X = m->X.as<float>();
   void* A = m->Abuf.p;
   void* Y = m->Ybuf.p;
+  void* Cp = m->Cpad.p;
   const bool y_bf16 = false;  // GEMM1 / conv results feed a LayerNorm: kept fp32 in both precisions
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerW& w = m->layers[i];
     int rc;
-    if ((rc = run_ln(m, X, false, A, h, w.ln1_g, w.ln1_b, rows, D, L, act, s))) return rc;
-    GemmProblem g1{A, L, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, B, L, H, D, 1, 1, h, y_bf16};
+    // the 1x1 projections are row-independent: tile them over all B*L rows as one long sequence
+    if ((rc = run_ln(m, X, false, A, h, w.ln1_g, w.ln1_b, rows, D, L, L, 0, act, s))) return rc;
+    GemmProblem g1{A, rows, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows, H, D, 1, 1, h, y_bf16};
     if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
-    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln2_g, w.ln2_b, rows, H, L, act, s))) return rc;
-    GemmProblem gc{A, L, 0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr, B, L, H, H,
-                   c.kernel_size, w.dilation, h, y_bf16};
+    if ((rc = run_ln(m, Y, y_bf16, Cp, h, w.ln2_g, w.ln2_b, rows, H, L, m->conv_pitch, m->conv_row0, act, s))) return rc;
+    GemmProblem gc{Cp, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
+                   B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
     if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
-    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows, H, L, act, s))) return rc;
-    GemmProblem g2{A, L, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, X, X, B, L, D, H, 1, 1, h, false};
+    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows, H, L, L, 0, act, s))) return rc;
+    GemmProblem g2{A, rows, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, X, X, 1, rows, D, H, 1, 1, h, false};
     if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s))) return rc;
     if (acts)
       HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows * D, X, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));

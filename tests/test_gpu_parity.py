@@ -23,6 +23,9 @@ DRAW_MARGIN_BF16 = 5e-2
 TINY = dict(d_embed=8, d_model=64, n_layers=8, kernel_size=5, r=128, slim=True, activation="gelu")
 TINY_WIDE = dict(d_embed=8, d_model=256, n_layers=9, kernel_size=5, r=128, slim=False, activation="gelu")
 MID = dict(d_embed=8, d_model=384, n_layers=10, kernel_size=5, r=128, slim=True, activation="gelu")
+# shapes the tuned bf16 kernel takes: N in {256, 512} (BN=256) and N = 640 (BN=320)
+BIG512 = dict(d_embed=8, d_model=512, n_layers=9, kernel_size=5, r=128, slim=True, activation="gelu")
+BIG640 = dict(d_embed=8, d_model=640, n_layers=8, kernel_size=5, r=128, slim=False, activation="gelu")
 
 
 @pytest.fixture(scope="module")
@@ -84,7 +87,8 @@ def test_time_encoding_quirk_against_reference_golden(golden_dir, dev):
 
 
 @pytest.mark.parametrize("cfg,B,L", [(MID, 3, 1), (MID, 3, 37), (MID, 2, 128), (MID, 2, 300), (TINY_WIDE, 1, 513),
-                                     (TINY_WIDE, 5, 256)])
+                                     (TINY_WIDE, 5, 256), (BIG512, 9, 300), (BIG512, 3, 256), (BIG640, 4, 512),
+                                     (BIG640, 16, 130), (BIG640, 1, 1024), (BIG640, 5, 77)])
 def test_forward_vs_oracle_shapes(dev, cfg, B, L):
     """Ragged and edge lengths: L=1, L below/at/above the 128-row tile, L > 2*max dilation."""
     oracle = R.build_model(cfg, None, 21)
