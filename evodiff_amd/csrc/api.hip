@@ -91,7 +91,7 @@ struct ed_model {
   std::vector<LayerW> layers;
 
   // workspace
-  int ws_B = 0, ws_L = 0;
+  int ws_B = 0, ws_L = 0, ws_prec = -1;
   DevBuf X, Abuf, Ybuf, Cpad, state, tok, order, uni, qbuf, tvec;
   long conv_pitch = 0, conv_row0 = 0;  // layout of Cpad: [B][conv_pitch][d_hidden], position 0 at row conv_row0
   hipStream_t cap_stream = nullptr;
@@ -227,7 +227,7 @@ int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, 
   return ED_OK;
 }
 
-int ensure_workspace(ed_model* m, int B, int L) {
+int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   const ed_config& c = m->cfg;
   const size_t rows = (size_t)B * L + 256;  // slack rows: tile loads may run past the last sequence
   const size_t Cmax = (size_t)std::max(c.d_model, c.d_hidden);
@@ -249,12 +249,13 @@ int ensure_workspace(ed_model* m, int B, int L) {
   const long halo = (long)(c.kernel_size / 2) * max_dil;
   const long pitch = halo + ((L + 255) / 256) * 256L + halo;
   const size_t cbytes = (size_t)B * pitch * c.d_hidden * 4;
-  const bool relayout = B != m->ws_B || L != m->ws_L || pitch != m->conv_pitch || cbytes > m->Cpad.bytes;
+  // the element size (and with it every row's byte position) differs between the two precisions
+  const bool relayout = B != m->ws_B || L != m->ws_L || prec != m->ws_prec || pitch != m->conv_pitch ||
+                        cbytes > m->Cpad.bytes;
   HIP_TRY(need(m->Cpad, cbytes));
-  if (relayout) {
-    HIP_TRY(hipMemset(m->Cpad.p, 0, m->Cpad.bytes));
-    grew = true;  // the graphs bake the pitch in
-  }
+  if (relayout) HIP_TRY(hipMemsetAsync(m->Cpad.p, 0, m->Cpad.bytes, s));
+  if (pitch != m->conv_pitch) grew = true;  // the graphs bake the pitch in
+  m->ws_prec = prec;
   m->conv_pitch = pitch;
   m->conv_row0 = halo;
   if (grew) m->drop_graphs();  // captured graphs hold the old pointers
@@ -552,7 +553,7 @@ int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* ti
   if (m->cfg.timesteps > 0 && !timesteps_dev) return fail(ED_EINVAL, "timesteps_dev is required for a model with timestep encoding");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
-  if ((rc = ensure_workspace(m, B, L))) return rc;
+  if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   m->probing_now = m->probe_every > 0;
   rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, s);
   if (!rc && acts_dev)
@@ -583,7 +584,7 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
   if (n_draw < 1 || n_draw > m->cfg.n_tokens) return fail(ED_EINVAL, "n_draw must be in [1, n_tokens]");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
-  if ((rc = ensure_workspace(m, B, L))) return rc;
+  if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
   // positions are validated on the host before any kernel indexes with them
   std::vector<int32_t> ord((size_t)n_steps);
@@ -619,7 +620,7 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
   if (n_steps < 0 || n_steps > t_start) return fail(ED_EINVAL, "n_steps must be in [0, t_start] (t runs down to 1)");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
-  if ((rc = ensure_workspace(m, B, L))) return rc;
+  if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
   // x_t indexes Q's columns: validate the token range on the host first
   {

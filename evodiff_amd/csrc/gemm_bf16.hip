@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   const long row_bytes = (long)g.K * 2;
   const char* a_src = (const char*)g.A + (((long)b * g.a_seq_pitch + g.a_row0 + l0 + wid * 32 + srow) * g.K) * 2;
   const char* w_src = (const char*)g.W + ((long)(n0 + wid * (NGB * 8) + srow) * g.K) * 2;
-  const int a_ch[2] = {(pch ^ sw_hi) * 16, (pch ^ (4 + sw_hi)) * 16};  // group parity 0 / 1
+  const int a_ch0 = (pch ^ sw_hi) * 16, a_ch1 = (pch ^ (4 + sw_hi)) * 16;  // 8-row group parity 0 / 1
 
   auto stage = [&](int s, int it) {
     const int tap = it / ksteps;
@@ -83,11 +83,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     const char* wp = w_src + (long)tap * g.N * row_bytes + kk * ROW_B;
 #pragma unroll
     for (int j = 0; j < 4; ++j)  // A rows wid*32 + 8j .. +8
-      glds16(ap + (long)(8 * j) * row_bytes + a_ch[j & 1], la + (wid * 4 + j) * 1024);
+      glds16(ap + (long)(8 * j) * row_bytes + ((j & 1) ? a_ch1 : a_ch0), la + (wid * 4 + j) * 1024);
 #pragma unroll
     for (int j = 0; j < NGB; ++j) {  // W rows n0 + 8*(wid*NGB + j) .. +8
       const int par = (wid * NGB + j) & 1;
-      glds16(wp + (long)(8 * j) * row_bytes + (par ? a_ch[1] : a_ch[0]), lb + (wid * NGB + j) * 1024);
+      glds16(wp + (long)(8 * j) * row_bytes + (par ? a_ch1 : a_ch0), lb + (wid * NGB + j) * 1024);
     }
   };
 
