@@ -650,6 +650,26 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
   return ED_OK;
 }
 
+int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const void* W_dev, const float* bias_dev,
+                  void* out_dev, const float* resid_dev, int B, int L, int N, int K, int ntaps, int dilation,
+                  int a_bf16, int out_bf16, int kernel, void* stream) {
+  if (!A_dev || !W_dev || !bias_dev || !out_dev) return fail(ED_EINVAL, "null pointer");
+  if (B <= 0 || L <= 0 || N <= 0 || K <= 0 || ntaps < 1 || !(ntaps & 1) || dilation < 1)
+    return fail(ED_EINVAL, "bad GEMM shape");
+  if (resid_dev && out_bf16) return fail(ED_EINVAL, "a residual add requires fp32 output");
+  if (K % (a_bf16 ? 32 : 16)) return fail(ED_EINVAL, "K must be a multiple of %d", a_bf16 ? 32 : 16);
+  GemmProblem p{A_dev, (long)a_seq_pitch, (long)a_row0, W_dev, bias_dev, out_dev, resid_dev, B, L, N, K, ntaps,
+                dilation, a_bf16 != 0, out_bf16 != 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (kernel == 2 || (kernel == 0 && gemm_bf16_supported(p))) {
+    if (!gemm_bf16_supported(p)) return fail(ED_EINVAL, "shape outside the tuned bf16 kernel's contract");
+    LAUNCH_TRY(launch_gemm_bf16(p, s));
+  } else {
+    LAUNCH_TRY(launch_gemm_generic(p, s));
+  }
+  return ED_OK;
+}
+
 int ed_probe_config(ed_model* m, int every_n_steps) {
   if (!m) return fail(ED_EINVAL, "null model handle");
   if (every_n_steps < 0) return fail(ED_EINVAL, "every_n_steps must be >= 0");

@@ -19,9 +19,12 @@
 // the convolution is laid out per sequence with zeroed halo rows in front and behind (a_row0, a_seq_pitch),
 // so a shifted tile is a plain contiguous row range and 'same' padding costs no bounds logic.  Work that is
 // provably zero is skipped at two levels: taps whose whole 256-row tile lies outside [0, L) are dropped from
-// the K loop, and a wave drops the MFMAs of any 32-row fragment that lies outside for the current tap
-// (at L = 256, dilation 128 this removes 3 of 5 taps' worth of MFMA work).
+// the K loop, and a wave skips a K-step when all 64 of its rows lie outside for the current tap (at L = 256,
+// dilation 128 this removes 3 of 5 taps' worth of MFMA work; finer, per-fragment skipping was measured to
+// cost more in register pressure than it saves).
 #include "kernels.hpp"
+
+#include <type_traits>
 
 namespace ed {
 
@@ -104,6 +107,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   const int a_rd = (wr * 64 + fr) * ROW_B;
   const int b_rd = (wc * (BN / 2) + fr) * ROW_B;
 
+  // One K-step of MFMA work for this wave.  LIVE0/LIVE1: which of the wave's two 32-row fragments have any
+  // row inside [0, L) for the current tap (compile-time here, so the body is one straight-line block the
+  // scheduler can software-pipeline: fragments of k-slice ks+1 are read while slice ks is multiplied).
+  auto kstep = [&](const char* la, const char* lb, auto live0_t, auto live1_t) {
+    constexpr bool LIVE0 = decltype(live0_t)::value, LIVE1 = decltype(live1_t)::value;
+    bf16x8 fa0[2], fa1[2], fb[2][NT];
+    auto load = [&](int ks, int buf) {
+      const int ch = ((2 * ks + fh) ^ fsw) * 16;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[buf][j] = *(const bf16x8*)(lb + b_rd + j * 32 * ROW_B + ch);
+      if constexpr (LIVE0) fa0[buf] = *(const bf16x8*)(la + a_rd + ch);
+      if constexpr (LIVE1) fa1[buf] = *(const bf16x8*)(la + a_rd + 32 * ROW_B + ch);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) load(ks + 1, (ks + 1) & 1);
+      if constexpr (LIVE0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[ks & 1], fb[ks & 1][j], acc[0][j], 0, 0, 0);
+      }
+      if constexpr (LIVE1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[ks & 1], fb[ks & 1][j], acc[1][j], 0, 0, 0);
+      }
+    }
+    // Pin the interleave for the whole K-step (one scheduling region): the 7 fragment reads of slice 0,
+    // then one read of slice ks+1 behind each of the first 7 MFMAs of slice ks, so reads are long complete
+    // when their MFMAs come up (left alone, hipcc batches reads, waits for all, then batches MFMAs).
+    __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+      for (int q = 0; q < NT + 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NT - 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
   if (it_begin < it_end) stage(0, it_begin);
   __syncthreads();
 
@@ -112,29 +161,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     if (it + 1 < it_end) stage(cur ^ 1, it + 1);
     const int tap = it / ksteps;
     const int shift = l0 + wr * 64 + (tap - half_taps) * g.dilation;  // first A position of this wave's rows
-    const bool live0 = shift + 32 > 0 && shift < g.L;
-    const bool live1 = shift + 64 > 0 && shift + 32 < g.L;
+    const bool live = shift + 64 > 0 && shift < g.L;  // any of the wave's 64 rows inside [0, L) for this tap
     const char* la = lds + cur * STAGE;
     const char* lb = la + A_BYTES;
-    if (live0 || live1) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ch = ((2 * ks + fh) ^ fsw) * 16;
-        bf16x8 fb[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *(const bf16x8*)(lb + b_rd + j * 32 * ROW_B + ch);
-        if (live0) {
-          const bf16x8 fa = *(const bf16x8*)(la + a_rd + ch);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[0][j], 0, 0, 0);
-        }
-        if (live1) {
-          const bf16x8 fa = *(const bf16x8*)(la + a_rd + 32 * ROW_B + ch);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[1][j], 0, 0, 0);
-        }
-      }
-    }
+    if (live) kstep(la, lb, T_{}, T_{});
     __syncthreads();  // next stage landed (the barrier's fence drains the DMA), this stage free to overwrite
   }
 

@@ -123,6 +123,15 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
 int ed_probe_config(ed_model* m, int every_n_steps);
 int ed_probe_read(ed_model* m, ed_probe_stat* stats, void* stream);
 
+/* Kernel-level test/benchmark hook (no counterpart in the reference): runs ONE implicit-GEMM problem
+ *   out[b*L + l][n] = bias[n] (+ resid[b*L + l][n]) + sum_{tap,k} A[b*a_seq_pitch + a_row0 + l + (tap - ntaps/2)*dilation][k] * W[tap][n][k]
+ * on caller-owned device buffers (A, W bf16 when a_bf16 != 0, else fp32; rows of A outside [0, L) of a
+ * sequence must be readable and zero when ntaps > 1).  kernel: 0 = the library's own choice, 1 = generic
+ * tile kernel, 2 = tuned bf16 kernel (fails with ED_EINVAL if the shape is outside its contract). */
+int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const void* W_dev, const float* bias_dev,
+                  void* out_dev, const float* resid_dev, int B, int L, int N, int K, int ntaps, int dilation,
+                  int a_bf16, int out_bf16, int kernel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
