@@ -661,6 +661,10 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   GemmProblem p{A_dev, (long)a_seq_pitch, (long)a_row0, W_dev, bias_dev, out_dev, resid_dev, B, L, N, K, ntaps,
                 dilation, a_bf16 != 0, out_bf16 != 0};
   hipStream_t s = (hipStream_t)stream;
+  if (kernel >= 3) {  // diagnostic ablations of the tuned kernel (3: no MFMAs, 4: no DMA); results are not valid
+    p.ablate = kernel - 2;
+    kernel = 2;
+  }
   if (kernel == 2 || (kernel == 0 && gemm_bf16_supported(p))) {
     if (!gemm_bf16_supported(p)) return fail(ED_EINVAL, "shape outside the tuned bf16 kernel's contract");
     LAUNCH_TRY(launch_gemm_bf16(p, s));

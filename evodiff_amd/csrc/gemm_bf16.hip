@@ -7,24 +7,26 @@
 // accumulators per lane).  640M has N = 1280 = 4 x 320 and config 2 has 64 row tiles, i.e. exactly one
 // tile per CU of the 256-CU chip with no tail; N = 512 / 1024 (38M) use BN = 256.
 //
-// K loop.  K runs over (tap, 64-channel slice).  Both operand tiles of a K-step are copied global -> LDS
-// by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile rows per wave-instruction) into one of two LDS
-// stages, the copy of step t+1 in flight while step t is multiplied; one barrier per K-step.
-// The LDS image is lane-linear (a DMA cannot scatter), so the bank swizzle
-// (16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7)) is applied to the per-lane SOURCE
-// address and again on the ds_read_b128 fragment reads: the 16 rows of every ds_read_b128 lane group then
-// fall on 16 different 16-byte slots of the 256-byte bank row (conflict-free).
+// K loop.  K runs over (tap, 64-channel slice) "steps".  The operand tiles of a step (256 + BN rows of 128
+// bytes = whole cache lines) are copied global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile
+// rows per wave-instruction) into one of two LDS stages, the copy of step t+1 in flight while step t is
+// multiplied; one barrier per step.  The issue order inside a step is pinned (sched_barrier after every
+// MFMA): behind each of the 40 (32) MFMAs of a step comes exactly one auxiliary instruction - one of the
+// 7 (6) fragment reads of the NEXT k-slice or one of the step's 9 (8) DMA copies - so neither the LDS read
+// latency nor the ~50-100-cycle issue cost of a copy ever opens an MFMA-free stretch in a wave.  (Left to
+// itself hipcc batches: all copies at the top of the step, then reads, a full wait, then MFMAs; with the two
+// waves of a SIMD in lockstep behind the same barrier that left the matrix pipe idle 45 % of the time.)
+//
+// LDS image.  A DMA cannot scatter (the image is lane-linear), so the bank swizzle - 16-byte chunk c of tile
+// row r is stored at chunk c ^ ((r >> 1) & 7) - is applied to the per-lane SOURCE address and again on the
+// ds_read_b128 fragment reads: the 16 rows of every ds_read_b128 lane group then fall on 16 different
+// 16-byte slots of the 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0 measured).
 //
 // Dilation halo.  A rows of tap t are the tile's rows shifted by (t - ntaps/2)*dilation.  The A buffer of
 // the convolution is laid out per sequence with zeroed halo rows in front and behind (a_row0, a_seq_pitch),
-// so a shifted tile is a plain contiguous row range and 'same' padding costs no bounds logic.  Work that is
-// provably zero is skipped at two levels: taps whose whole 256-row tile lies outside [0, L) are dropped from
-// the K loop, and a wave skips a K-step when all 64 of its rows lie outside for the current tap (at L = 256,
-// dilation 128 this removes 3 of 5 taps' worth of MFMA work; finer, per-fragment skipping was measured to
-// cost more in register pressure than it saves).
+// so a shifted tile is a plain contiguous row range and 'same' padding costs no bounds logic.  Taps whose
+// whole 256-row tile lies outside [0, L) are dropped from the K loop (at L = 256, dilation 128: 2 of 5 taps).
 #include "kernels.hpp"
-
-#include <type_traits>
 
 namespace ed {
 
@@ -33,18 +35,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
-constexpr int BM = 256, BK = 64, ROW_B = BK * 2;  // 128 bytes of K per tile row per K-step
+constexpr int BM = 256, BK = 64, ROW_B = BK * 2;  // 128 bytes of K per tile row per step
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int NT, bool OUT_BF16, bool RESID>
+// ABLATE (diagnostic builds, results invalid): 1 = no MFMAs, 2 = no DMA copies.
+template <int NT, bool OUT_BF16, bool RESID, int ABLATE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
-  constexpr int NGB = BN / 64;  // 8-row DMA groups of the B tile per wave
+  constexpr int NGB = BN / 64;      // 8-row DMA groups of the W tile per wave (A: 4 per wave)
+  constexpr int N_DMA = 4 + NGB;    // copies per wave per step
+  constexpr int N_RD = NT + 2;      // fragment reads per k-slice
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -68,30 +73,43 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   int tap_lo = 0, tap_hi = g.ntaps - 1;
   while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
   while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
-  const int it_begin = tap_lo * ksteps, it_end = (tap_hi + 1) * ksteps;
+  const int T = (tap_hi - tap_lo + 1) * ksteps;  // number of steps
 
-  // ---- DMA source addressing: lane -> (row in 8-row group, physical chunk); logical chunk = physical ^ swizzle
-  const int srow = lane >> 3, pch = lane & 7, sw_hi = lane >> 4;
+  // ---- DMA addressing.  Lane -> (row in 8-row group, physical chunk); logical chunk = physical ^ swizzle.
+  // Group bases are multiples of 8 rows, so (row >> 1) & 7 = 4 * (group parity) + (lane >> 4).
   const long row_bytes = (long)g.K * 2;
-  const char* a_src = (const char*)g.A + (((long)b * g.a_seq_pitch + g.a_row0 + l0 + wid * 32 + srow) * g.K) * 2;
-  const char* w_src = (const char*)g.W + ((long)(n0 + wid * (NGB * 8) + srow) * g.K) * 2;
-  const int a_ch0 = (pch ^ sw_hi) * 16, a_ch1 = (pch ^ (4 + sw_hi)) * 16;  // 8-row group parity 0 / 1
+  const unsigned lane_row = (unsigned)((lane >> 3) * row_bytes);
+  const unsigned lane_off0 = lane_row + (((lane & 7) ^ (lane >> 4)) << 4);
+  const unsigned lane_off1 = lane_row + (((lane & 7) ^ (4 + (lane >> 4))) << 4);
+  const unsigned grp_bytes = (unsigned)(8 * row_bytes);
+  // wave-uniform bases of the copy stream (this wave's first A / W group), advanced step by step
+  const char* a_dma = (const char*)g.A +
+                      ((long)b * g.a_seq_pitch + g.a_row0 + l0 + (long)(tap_lo - half_taps) * g.dilation + wid * 32) *
+                          row_bytes;
+  const char* w_dma = (const char*)g.W + ((long)tap_lo * g.N + n0 + wid * (NGB * 8)) * row_bytes;
+  const long a_tap_step = (long)(g.dilation - 1) * row_bytes + ROW_B, w_tap_step = (long)(g.N - 1) * row_bytes + ROW_B;
+  int dma_kk = 0, dma_t = 0;
 
-  auto stage = [&](int s, int it) {
-    const int tap = it / ksteps;
-    const int kk = it - tap * ksteps;
-    char* la = lds + s * STAGE;
-    char* lb = la + A_BYTES;
-    const char* ap = a_src + (long)(tap - half_taps) * g.dilation * row_bytes + kk * ROW_B;
-    const char* wp = w_src + (long)tap * g.N * row_bytes + kk * ROW_B;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)  // A rows wid*32 + 8j .. +8
-      glds16(ap + (long)(8 * j) * row_bytes + ((j & 1) ? a_ch1 : a_ch0), la + (wid * 4 + j) * 1024);
-#pragma unroll
-    for (int j = 0; j < NGB; ++j) {  // W rows n0 + 8*(wid*NGB + j) .. +8
-      const int par = (wid * NGB + j) & 1;
-      glds16(wp + (long)(8 * j) * row_bytes + (par ? a_ch1 : a_ch0), lb + (wid * NGB + j) * 1024);
+  // piece j (0 .. N_DMA-1) of the copy of step dma_t into stage dma_t & 1
+  auto dma_piece = [&](int j) {
+    if constexpr (ABLATE == 2) return;
+    char* st = lds + (dma_t & 1) * STAGE;
+    if (j < 4) {  // A rows wid*32 + 8j .. +8   (group wid*4 + j, parity j & 1)
+      glds16(a_dma + (unsigned)j * grp_bytes + ((j & 1) ? lane_off1 : lane_off0), st + (wid * 4 + j) * 1024);
+    } else {      // W rows n0 + 8*(wid*NGB + jj) .. +8
+      const int jj = j - 4, grp = wid * NGB + jj;
+      glds16(w_dma + (unsigned)jj * grp_bytes + ((grp & 1) ? lane_off1 : lane_off0), st + A_BYTES + grp * 1024);
     }
+  };
+  // Advance the copy stream to the next step (branch-free).  Past the last step it stalls on the last tile:
+  // those copies stay in bounds and land in a stage nobody reads any more.
+  auto dma_advance = [&]() {
+    ++dma_t;
+    const bool more = dma_t < T;
+    const bool wrap = dma_kk + 1 == ksteps;  // next tap: rows shift by dilation, channels back to 0
+    dma_kk = wrap ? 0 : dma_kk + 1;
+    a_dma += more ? (wrap ? a_tap_step : (long)ROW_B) : 0L;
+    w_dma += more ? (wrap ? w_tap_step : (long)ROW_B) : 0L;
   };
 
   f32x16 acc[2][NT];
@@ -102,70 +120,60 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- fragment read addressing (32x32x16: lane = (row fr, k-half fh) holds 8 consecutive k)
+  // ---- fragment addressing (32x32x16: lane = (row fr, k-half fh) holds 8 consecutive k)
   const int fr = lane & 31, fh = lane >> 5, fsw = (lane >> 1) & 7;
   const int a_rd = (wr * 64 + fr) * ROW_B;
-  const int b_rd = (wc * (BN / 2) + fr) * ROW_B;
+  const int b_rd = A_BYTES + (wc * (BN / 2) + fr) * ROW_B;
 
-  // One K-step of MFMA work for this wave.  LIVE0/LIVE1: which of the wave's two 32-row fragments have any
-  // row inside [0, L) for the current tap (compile-time here, so the body is one straight-line block the
-  // scheduler can software-pipeline: fragments of k-slice ks+1 are read while slice ks is multiplied).
-  auto kstep = [&](const char* la, const char* lb, auto live0_t, auto live1_t) {
-    constexpr bool LIVE0 = decltype(live0_t)::value, LIVE1 = decltype(live1_t)::value;
-    bf16x8 fa0[2], fa1[2], fb[2][NT];
-    auto load = [&](int ks, int buf) {
-      const int ch = ((2 * ks + fh) ^ fsw) * 16;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[buf][j] = *(const bf16x8*)(lb + b_rd + j * 32 * ROW_B + ch);
-      if constexpr (LIVE0) fa0[buf] = *(const bf16x8*)(la + a_rd + ch);
-      if constexpr (LIVE1) fa1[buf] = *(const bf16x8*)(la + a_rd + 32 * ROW_B + ch);
-    };
-    load(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) load(ks + 1, (ks + 1) & 1);
-      if constexpr (LIVE0) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[ks & 1], fb[ks & 1][j], acc[0][j], 0, 0, 0);
-      }
-      if constexpr (LIVE1) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[ks & 1], fb[ks & 1][j], acc[1][j], 0, 0, 0);
-      }
-    }
-    // Pin the interleave for the whole K-step (one scheduling region): the 7 fragment reads of slice 0,
-    // then one read of slice ks+1 behind each of the first 7 MFMAs of slice ks, so reads are long complete
-    // when their MFMAs come up (left alone, hipcc batches reads, waits for all, then batches MFMAs).
-    __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-#pragma unroll
-      for (int q = 0; q < NT + 2; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NT - 2, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+  bf16x8 fa[2][2], fb[2][NT];  // [k-slice parity][fragment]
+  // read r (0 .. N_RD-1) of k-slice ks: A rows 0-31 first (the first MFMAs need it), then W, A rows 32-63 last
+  auto read_piece = [&](const char* st, int ks, int r) {
+    const char* base = st + (((2 * ks + fh) ^ fsw) << 4);
+    if (r == 0) fa[ks & 1][0] = *(const bf16x8*)(base + a_rd);
+    else if (r <= NT) fb[ks & 1][r - 1] = *(const bf16x8*)(base + b_rd + (r - 1) * 32 * ROW_B);
+    else fa[ks & 1][1] = *(const bf16x8*)(base + a_rd + 32 * ROW_B);
   };
-  using T_ = std::true_type;
-  using F_ = std::false_type;
+  auto mfma_piece = [&](int ks, int q) {  // MFMA q (0 .. 2*NT-1) of k-slice ks
+    const int i = q / NT, j = q - i * NT;
+    if constexpr (ABLATE == 1) {
+      asm volatile("" ::"v"(fa[ks & 1][i]), "v"(fb[ks & 1][j]));  // keep the fragment reads alive
+    } else {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
 
-  if (it_begin < it_end) stage(0, it_begin);
-  __syncthreads();
+  if (T > 0) {
+    // prologue: copy of step 0
+#pragma unroll
+    for (int j = 0; j < N_DMA; ++j) dma_piece(j);
+    dma_advance();
+    __syncthreads();  // (its fence drains the DMA)
 
-  for (int it = it_begin; it < it_end; ++it) {
-    const int cur = (it - it_begin) & 1;
-    if (it + 1 < it_end) stage(cur ^ 1, it + 1);
-    const int tap = it / ksteps;
-    const int shift = l0 + wr * 64 + (tap - half_taps) * g.dilation;  // first A position of this wave's rows
-    const bool live = shift + 64 > 0 && shift < g.L;  // any of the wave's 64 rows inside [0, L) for this tap
-    const char* la = lds + cur * STAGE;
-    const char* lb = la + A_BYTES;
-    if (live) kstep(la, lb, T_{}, T_{});
-    __syncthreads();  // next stage landed (the barrier's fence drains the DMA), this stage free to overwrite
+    for (int t = 0; t < T; ++t) {
+      const char* st = lds + (t & 1) * STAGE;
+#pragma unroll
+      for (int r = 0; r < N_RD; ++r) read_piece(st, 0, r);
+      __builtin_amdgcn_sched_barrier(0);
+      // 4 k-slices x 2*NT MFMAs; behind each MFMA one auxiliary instruction: first the reads of the next
+      // slice, then (slots left over) the copies of step t+1 into the other stage
+      int dma_j = 0;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int q = 0; q < 2 * NT; ++q) {
+          mfma_piece(ks, q);
+          if (ks < 3 && q < N_RD) {
+            read_piece(st, ks + 1, q);
+          } else if (dma_j < N_DMA) {
+            dma_piece(dma_j);
+            ++dma_j;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      dma_advance();
+      __syncthreads();  // copy of step t+1 landed (fence drains the DMA); stage t free to be overwritten
+    }
   }
 
   // ---- epilogue: C[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -194,7 +202,9 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   const int tiles_n = p.N / (NT * 64);
   const int tiles_total = p.B * ((p.L + BM - 1) / BM) * tiles_n;
   const dim3 grid(tiles_total), block(512);
-  if (p.resid) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+  if (p.ablate == 1) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, false, 1>), grid, block, 0, stream, p, tiles_n, tiles_total);
+  else if (p.ablate == 2) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, false, 2>), grid, block, 0, stream, p, tiles_n, tiles_total);
+  else if (p.resid) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
   else if (p.out_bf16) hipLaunchKernelGGL((gemm_bf16_kernel<NT, true, false>), grid, block, 0, stream, p, tiles_n, tiles_total);
   else hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, false>), grid, block, 0, stream, p, tiles_n, tiles_total);
   return hipGetLastError();
@@ -208,7 +218,8 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
 bool gemm_bf16_supported(const GemmProblem& p) {
   if (!p.a_bf16 || p.K % BK != 0 || p.K < BK) return false;
   if (p.N % 320 != 0 && p.N % 256 != 0) return false;
-  if ((long)p.B * p.L < BM) return false;  // less than one 256-row tile: generic kernel
+  if ((long)p.B * p.L < BM) return false;               // less than one 256-row tile: generic kernel
+  if ((long)p.K * 2 * 64 >= (1L << 31)) return false;   // per-lane DMA offsets are 32-bit
   if (p.ntaps > 1 && p.a_row0 < (long)(p.ntaps / 2) * p.dilation) return false;
   if (p.resid && p.out_bf16) return false;
   return true;

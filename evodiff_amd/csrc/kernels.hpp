@@ -35,6 +35,7 @@ struct GemmProblem {
   int B, L, N, K, ntaps, dilation;
   bool a_bf16;          // element type of A and W
   bool out_bf16;        // element type of out (resid != nullptr requires fp32 out)
+  int ablate = 0;       // diagnostic builds of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong)
 };
 
 // Reference-quality tile kernel: any shape with K % 32 == 0 (bf16) / K % 16 == 0 (fp32).
