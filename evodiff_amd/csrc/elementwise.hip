@@ -21,6 +21,19 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU to ~2e-7 absolute (Abramowitz-Stegun 7.1.26 + hardware exp/rcp): a third of erff's
+// instructions.  Used where the result is rounded to bf16 (2^-9 relative) right after.
+__device__ __forceinline__ float gelu_bf16_grade(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = p * t * __expf(-z * z);   // 1 - erf(z)
+  const float erf_abs = 1.0f - e;
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // embed: evodiff/model.py:131-140
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in
                   fmaf(v[c][3], gm.w, bt.w)};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (act == 1) y[j] = gelu_exact(y[j]);
+      if (act == 1) y[j] = OUT_BF16 ? gelu_bf16_grade(y[j]) : gelu_exact(y[j]);
       else if (act == 2) y[j] = fmaxf(y[j], 0.f);
     }
     if constexpr (OUT_BF16) {

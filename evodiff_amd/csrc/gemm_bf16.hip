@@ -43,7 +43,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 // ABLATE (diagnostic builds, results invalid): 1 = no MFMAs, 2 = no DMA copies.
-template <int NT, bool OUT_BF16, bool RESID, int ABLATE = 0>
+template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
@@ -112,16 +112,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     w_dma += more ? (wrap ? w_tap_step : (long)ROW_B) : 0L;
   };
 
+  // Accumulators start at bias (+ residual): the epilogue is then a pure store, and the residual tile is
+  // fetched here, where its latency hides behind the first DMA wait, instead of serialising the store tail
+  // (measured: the add-in-the-epilogue form made the x += PFF2(...) GEMM 2x slower than the same GEMM without it).
+  const int fr = lane & 31, fh = lane >> 5;
+  const bool full_rows = l0 + BM <= g.L;  // no row masking needed (always true when 256 | L)
   f32x16 acc[2][NT];
+  {
+    const int nb = n0 + wc * (BN / 2) + fr;
+    float bias[NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NT; ++j) bias[j] = g.bias[nb + j * 32];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const bool on = full_rows || l < g.L;
+        const float* pr = RESID ? g.resid + ((long)b * g.L + l) * g.N + nb : nullptr;  // one address per row
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v = bias[j];
+          if constexpr (RESID)
+            if (on) v += pr[j * 32];
+          acc[i][j][r] = v;
+        }
+      }
+  }
 
   // ---- fragment addressing (32x32x16: lane = (row fr, k-half fh) holds 8 consecutive k)
-  const int fr = lane & 31, fh = lane >> 5, fsw = (lane >> 1) & 7;
+  const int fsw = (lane >> 1) & 7;
   const int a_rd = (wr * 64 + fr) * ROW_B;
   const int b_rd = A_BYTES + (wc * (BN / 2) + fr) * ROW_B;
 
@@ -176,37 +196,43 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     }
   }
 
-  // ---- epilogue: C[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // ---- epilogue: C[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // The row base is laundered through an empty asm so that the 32 row addresses are computed HERE: hoisted
+  // above the K loop as loop invariants (or shared with the residual loads) they cost 40-64 live registers.
+  int l0e = l0;
+  asm volatile("" : "+s"(l0e));
+  {
+    const int nb = n0 + wc * (BN / 2) + fr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wc * (BN / 2) + j * 32 + fr;
-      const float bias = g.bias[n];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (l < g.L) {
-          const long o = ((long)b * g.L + l) * g.N + n;
-          float v = acc[i][j][r] + bias;
-          if constexpr (RESID) v += g.resid[o];
-          if constexpr (OUT_BF16) ((bf16_t*)g.out)[o] = f32_to_bf16_bits(v);
-          else ((float*)g.out)[o] = v;
+        const int l = l0e + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (full_rows || l < g.L) {
+          const long o = ((long)b * g.L + l) * g.N + nb;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if constexpr (OUT_BF16) ((bf16_t*)g.out)[o + j * 32] = f32_to_bf16_bits(acc[i][j][r]);
+            else ((float*)g.out)[o + j * 32] = acc[i][j][r];
+          }
         }
       }
-    }
+  }
 }
 
-template <int NT>
+template <int NT, bool CONV>
 hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   const int tiles_n = p.N / (NT * 64);
   const int tiles_total = p.B * ((p.L + BM - 1) / BM) * tiles_n;
   const dim3 grid(tiles_total), block(512);
-  if (p.ablate == 1) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, false, 1>), grid, block, 0, stream, p, tiles_n, tiles_total);
-  else if (p.ablate == 2) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, false, 2>), grid, block, 0, stream, p, tiles_n, tiles_total);
-  else if (p.resid) hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
-  else if (p.out_bf16) hipLaunchKernelGGL((gemm_bf16_kernel<NT, true, false>), grid, block, 0, stream, p, tiles_n, tiles_total);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<NT, false, false>), grid, block, 0, stream, p, tiles_n, tiles_total);
+#define ED_GO(OB, RS, AB) \
+  hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB>), grid, block, 0, stream, p, tiles_n, tiles_total)
+  if (p.ablate == 1) ED_GO(false, false, 1);
+  else if (p.ablate == 2) ED_GO(false, false, 2);
+  else if (p.resid) ED_GO(false, true, 0);
+  else if (p.out_bf16) ED_GO(true, false, 0);
+  else ED_GO(false, false, 0);
+#undef ED_GO
   return hipGetLastError();
 }
 
@@ -227,7 +253,8 @@ bool gemm_bf16_supported(const GemmProblem& p) {
 
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream) {
   if (!gemm_bf16_supported(p)) return hipErrorInvalidValue;
-  return p.N % 320 == 0 ? launch_nt<5>(p, stream) : launch_nt<4>(p, stream);
+  if (p.ntaps > 1) return p.N % 320 == 0 ? launch_nt<5, true>(p, stream) : launch_nt<4, true>(p, stream);
+  return p.N % 320 == 0 ? launch_nt<5, false>(p, stream) : launch_nt<4, false>(p, stream);
 }
 
 }  // namespace ed
