@@ -274,7 +274,9 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, hipStream_t s) 
   void* A = m->Abuf.p;
   void* Y = m->Ybuf.p;
   void* Cp = m->Cpad.p;
-  const bool y_bf16 = false;  // GEMM1 / conv results feed a LayerNorm: kept fp32 in both precisions
+  // GEMM1 / conv results feed a LayerNorm straight away; in the fast path they are stored as bf16 (the
+  // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
+  const bool y_bf16 = h;
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerW& w = m->layers[i];
     int rc;

@@ -43,7 +43,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 // ABLATE (diagnostic builds, results invalid): 1 = no MFMAs, 2 = no DMA copies.
-template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0>
+// RT > 0 (1x1 + residual only): the K loop has exactly RT steps and is fully unrolled, and the residual tile is
+// streamed in DURING the loop (see below) instead of before it.
+template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float v = bias[j];
-          if constexpr (RESID)
+          if constexpr (RESID && RT == 0)
             if (on) v += pr[j * 32];
           acc[i][j][r] = v;
         }
@@ -169,13 +171,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     dma_advance();
     __syncthreads();  // (its fence drains the DMA)
 
-    for (int t = 0; t < T; ++t) {
+    // One step: 4 k-slices x 2*NT MFMAs; behind each MFMA one auxiliary instruction: first the reads of the
+    // next slice, then (slots left over) the copies of step t+1 into the other stage.
+    auto step = [&](int t) {
       const char* st = lds + (t & 1) * STAGE;
 #pragma unroll
       for (int r = 0; r < N_RD; ++r) read_piece(st, 0, r);
       __builtin_amdgcn_sched_barrier(0);
-      // 4 k-slices x 2*NT MFMAs; behind each MFMA one auxiliary instruction: first the reads of the next
-      // slice, then (slots left over) the copies of step t+1 into the other stage
       int dma_j = 0;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -193,6 +195,45 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
       }
       dma_advance();
       __syncthreads();  // copy of step t+1 landed (fence drains the DMA); stage t free to be overwritten
+    };
+
+    if constexpr (RESID && RT > 0) {
+      // Residual tile hidden inside the K loop.  The x += PFF2(...) GEMM would otherwise read its 256 x BN fp32
+      // tile either before the loop or in the epilogue, in both cases with every CU doing it at the same time
+      // and no MFMA running (measured: +40 us on a 60 us GEMM).  Here step t issues the loads of CPS accumulator
+      // tiles' worth of residual (16 dwords per lane each) right after the barrier, and step t+1 adds them into
+      // the accumulators before its first MFMA: the loads fly under a whole step of MFMAs and are retired by
+      // the step's own end-of-step wait.
+      constexpr int NVAL = 32 * NT;                       // residual values per lane
+      constexpr int VPG = ((NVAL + RT - 1) / RT + 7) & ~7;  // values per group (one group per step), 8 or 16
+      constexpr int NG = (NVAL + VPG - 1) / VPG;          // groups: group g is loaded during step g-1, added in step g
+      static_assert(NG <= RT, "K loop too short to hide the residual tile");
+      // wave-uniform base + one 32-bit per-lane offset: the loads then need no per-element address registers
+      const float* rbase = g.resid + ((long)b * g.L + l0 + wr * 64) * g.N + n0 + wc * (BN / 2);
+      const unsigned rlane = (unsigned)(4 * fh * g.N + fr);
+      float rv[VPG];
+      auto load_group = [&](int grp) {
+#pragma unroll
+        for (int v = 0; v < VPG; ++v) {
+          const int e = grp * VPG + v, c = e >> 4, r = e & 15;  // accumulator tile c = (i, j), register r
+          if (e < NVAL) rv[v] = (rbase + (long)((c / NT) * 32 + (r & 3) + 8 * (r >> 2)) * g.N + (c % NT) * 32)[rlane];
+        }
+      };
+      load_group(0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        if (t < NG) {
+#pragma unroll
+          for (int v = 0; v < VPG; ++v) {
+            const int e = t * VPG + v, c = e >> 4, r = e & 15;
+            if (e < NVAL) acc[c / NT][c % NT][r] += rv[v];
+          }
+          if (t + 1 < NG) load_group(t + 1);
+        }
+        step(t);
+      }
+    } else {
+      for (int t = 0; t < T; ++t) step(t);
     }
   }
 
@@ -229,7 +270,15 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB>), grid, block, 0, stream, p, tiles_n, tiles_total)
   if (p.ablate == 1) ED_GO(false, false, 1);
   else if (p.ablate == 2) ED_GO(false, false, 2);
-  else if (p.resid) ED_GO(false, true, 0);
+  else if (p.resid) {
+    // hidden-residual form: 1x1, every tile full, K loop of a known length
+    const bool whole = !CONV && ((long)p.B * p.L) % BM == 0 && (p.B == 1 || p.L % BM == 0);
+    if (whole && p.K == 20 * BK)
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 20>), grid, block, 0, stream, p, tiles_n, tiles_total);
+    else if (whole && NT == 4 && p.K == 8 * BK)
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 8>), grid, block, 0, stream, p, tiles_n, tiles_total);
+    else ED_GO(false, true, 0);
+  }
   else if (p.out_bf16) ED_GO(true, false, 0);
   else ED_GO(false, false, 0);
 #undef ED_GO
