@@ -14,7 +14,7 @@ KIND_NAMES = ("embed", "ln_act", "gemm1x1", "conv", "final")
 # every symbol include/evodiff_hip.h declares
 SYMBOLS = ("ed_abi_version", "ed_last_error", "ed_model_create", "ed_model_destroy", "ed_model_load_tensor",
            "ed_model_commit", "ed_model_num_params", "ed_forward", "ed_forward_collect", "ed_oadm_sample",
-           "ed_d3pm_sample", "ed_probe_config", "ed_probe_read", "ed_debug_gemm")
+           "ed_d3pm_sample", "ed_probe_config", "ed_probe_read", "ed_debug_gemm", "ed_debug_ln_act")
 
 
 class EdConfig(C.Structure):
@@ -58,6 +58,7 @@ def load():
     lib.ed_oadm_sample.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
     lib.ed_d3pm_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
     lib.ed_debug_gemm.argtypes = [vp, i64, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.ed_debug_ln_act.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.ed_probe_config.argtypes = [vp, i32]
     lib.ed_probe_read.argtypes = [vp, C.POINTER(EdProbeStat), vp]
     if lib.ed_abi_version() != 1:

@@ -676,6 +676,15 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   return ED_OK;
 }
 
+int ed_debug_ln_act(const void* in_dev, int in_bf16, void* out_dev, int out_bf16, const float* gamma_dev,
+                    const float* beta_dev, int rows, int C, int act, void* stream) {
+  if (!in_dev || !out_dev || !gamma_dev || !beta_dev) return fail(ED_EINVAL, "null pointer");
+  if (rows <= 0 || C <= 0 || C % 4 || C > 2048 || act < 0 || act > 2) return fail(ED_EINVAL, "bad LayerNorm shape");
+  LAUNCH_TRY(launch_ln_act(in_dev, in_bf16 != 0, out_dev, out_bf16 != 0, gamma_dev, beta_dev, rows, C, rows, rows, 0,
+                           act, (hipStream_t)stream));
+  return ED_OK;
+}
+
 int ed_probe_config(ed_model* m, int every_n_steps) {
   if (!m) return fail(ED_EINVAL, "null model handle");
   if (every_n_steps < 0) return fail(ED_EINVAL, "every_n_steps must be >= 0");

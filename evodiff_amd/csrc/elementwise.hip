@@ -94,6 +94,33 @@ __device__ __forceinline__ void load_row(const void* in, long row, int C, int la
   }
 }
 
+// Fast-path statistics: sum and sum of squares in ONE cross-lane reduction round (two independent shuffle
+// chains instead of two dependent ones); var = E[x^2] - mean^2 in fp32 is exact enough ahead of a bf16 store.
+template <int NCH>
+__device__ __forceinline__ void normalize_row_onepass(float (&v)[NCH][4], int C, int lane) {
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s += v[c][j];
+      q = fmaf(v[c][j], v[c][j], q);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  const float inv = 1.0f / (float)C;
+  const float mean = s * inv;
+  const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + LN_EPS);
+  const float shift = -mean * rstd;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[c][j] = fmaf(v[c][j], rstd, shift);
+}
+
 // (v - mean) * rstd in place; mean and biased variance over C as nn.LayerNorm computes them.
 template <int NCH>
 __device__ __forceinline__ void normalize_row(float (&v)[NCH][4], int C, int lane) {
@@ -128,7 +155,8 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in
   if (row >= rows) return;
   float v[NCH][4];
   load_row<NCH, IN_BF16>(in, row, C, lane, v);
-  normalize_row<NCH>(v, C, lane);
+  if constexpr (OUT_BF16) normalize_row_onepass<NCH>(v, C, lane);
+  else normalize_row<NCH>(v, C, lane);
   const long orow = (row / L) * out_pitch + out_row0 + (row % L);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -144,10 +172,9 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in
       else if (act == 2) y[j] = fmaxf(y[j], 0.f);
     }
     if constexpr (OUT_BF16) {
-      uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16_bits(y[0]) | ((uint32_t)f32_to_bf16_bits(y[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16_bits(y[2]) | ((uint32_t)f32_to_bf16_bits(y[3]) << 16);
-      *(uint2*)((bf16_t*)out + orow * C + idx) = pk;
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+      const bf16x4 pk = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};  // v_cvt_pk_bf16_f32 (RNE)
+      *(bf16x4*)((bf16_t*)out + orow * C + idx) = pk;
     } else {
       *(float4*)((float*)out + orow * C + idx) = make_float4(y[0], y[1], y[2], y[3]);
     }

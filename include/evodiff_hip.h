@@ -132,6 +132,11 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
                   void* out_dev, const float* resid_dev, int B, int L, int N, int K, int ntaps, int dilation,
                   int a_bf16, int out_bf16, int kernel, void* stream);
 
+/* Kernel-level test/benchmark hook (no counterpart in the reference): out = act(LayerNorm(in)) row-wise,
+ * in/out fp32 or bf16 [rows][C], act 0 none / 1 exact-erf GELU / 2 ReLU. */
+int ed_debug_ln_act(const void* in_dev, int in_bf16, void* out_dev, int out_bf16, const float* gamma_dev,
+                    const float* beta_dev, int rows, int C, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
