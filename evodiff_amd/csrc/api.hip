@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -63,6 +64,15 @@ struct LayerW {
   const bf16_t *w1_h, *wc_h, *w2_h;                                           // bf16 matrices
 };
 
+// Dependency-cone pruning (OA-DM only): a step reads the network output at ONE position pos, so a layer only has to
+// produce the positions its successors read.  Walking back from the output, a layer with dilation d whose output
+// is needed on {p : p = pos mod s_out} reads its input on {p : p = pos mod gcd(s_out, d)}; such position sets are
+// stored compactly (L / s rows per sequence, row m = position (pos mod s) + m*s).
+struct LayerPlan {
+  int s_in = 1, s_out = 1;  // 1 = every position
+  long cp_row = 0;          // first row of this layer's compact convolution input inside Cprune (s_in > 1)
+};
+
 struct GraphKey {
   int mode, B, L, prec, n;
   bool operator<(const GraphKey& o) const {
@@ -92,7 +102,11 @@ struct ed_model {
 
   // workspace
   int ws_B = 0, ws_L = 0, ws_prec = -1;
-  DevBuf X, Abuf, Ybuf, Cpad, state, tok, order, uni, qbuf, tvec;
+  DevBuf X, X2, Abuf, Ybuf, Cpad, Cprune, state, tok, order, uni, qbuf, tvec;
+  bool prune = true;           // ED_OPT_PRUNE
+  int min_tuned_tiles = 96;    // ED_OPT_MIN_TUNED_TILES
+  std::vector<LayerPlan> plan; // per layer, for the current (B, L)
+  int plan_s_final = 1;        // stride of the position set the last block produces
   long conv_pitch = 0, conv_row0 = 0;  // layout of Cpad: [B][conv_pitch][d_hidden], position 0 at row conv_row0
   hipStream_t cap_stream = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -199,10 +213,18 @@ struct Probe {
                                       __FILE__, __LINE__);                                               \
   } while (0)
 
+// The tuned kernel works on 256-row x 256/320-column tiles, one per CU at a time: a problem with few such tiles
+// leaves most of the chip idle, and the small-tile generic kernel is the faster one.
+bool use_tuned_gemm(const ed_model* m, const GemmProblem& p) {
+  if (!p.a_bf16 || !gemm_bf16_supported(p)) return false;
+  const long tiles = (long)p.B * ((p.L + 255) / 256) * (p.N % 320 == 0 ? p.N / 320 : p.N / 256);
+  return tiles >= m->min_tuned_tiles;
+}
+
 int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
-  if (p.a_bf16 && gemm_bf16_supported(p)) LAUNCH_TRY(launch_gemm_bf16(p, s));
+  if (use_tuned_gemm(m, p)) LAUNCH_TRY(launch_gemm_bf16(p, s));
   else LAUNCH_TRY(launch_gemm_generic(p, s));
   double taps = 0;
   for (int t = 0; t < p.ntaps; ++t) {
@@ -219,10 +241,10 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
 }
 
 int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, const float* g, const float* b,
-           int rows, int C, int L, long out_pitch, long out_row0, int act, hipStream_t s) {
+           int rows, int C, const LnRowMap& map, int act, hipStream_t s) {
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
-  LAUNCH_TRY(launch_ln_act(in, in_bf16, out, out_bf16, g, b, rows, C, L, out_pitch, out_row0, act, s));
+  LAUNCH_TRY(launch_ln_act(in, in_bf16, out, out_bf16, g, b, rows, C, map, act, s));
   LAUNCH_TRY(pr.end(ED_K_LNACT, 0.0, (double)rows * C * ((in_bf16 ? 2.0 : 4.0) + (out_bf16 ? 2.0 : 4.0))));
   return ED_OK;
 }
@@ -254,6 +276,36 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
                         cbytes > m->Cpad.bytes;
   HIP_TRY(need(m->Cpad, cbytes));
   if (relayout) HIP_TRY(hipMemsetAsync(m->Cpad.p, 0, m->Cpad.bytes, s));
+  // pruning plan for this L (see LayerPlan) and the compact convolution inputs it needs, one zero-initialised
+  // region per pruned layer: [gap zeros | B x (L/s_in rows | gap zeros) | tile slack]
+  m->plan.assign((size_t)c.n_layers, LayerPlan{});
+  m->plan_s_final = 1;
+  long prune_rows = 0;
+  if (m->prune) {
+    int sset = 1;
+    while (sset < (1 << 20) && L % (2 * sset) == 0) sset *= 2;  // largest power of two dividing L
+    m->plan_s_final = sset;
+    for (int i = c.n_layers - 1; i >= 0 && sset > 1; --i) {
+      const int d = m->layers[i].dilation;
+      int s_in = std::gcd(sset, d);
+      long gap = (long)(c.kernel_size / 2) * (d / s_in);
+      if (gap > L / s_in) s_in = 1;  // more padding than data: read every position instead
+      LayerPlan& pl = m->plan[i];
+      pl.s_out = sset;
+      pl.s_in = s_in;
+      if (s_in > 1) {
+        pl.cp_row = prune_rows;
+        const long body = (long)B * (L / s_in + gap);
+        prune_rows += gap + ((body + 255) / 256) * 256 + gap + 256;
+      }
+      sset = s_in;
+    }
+  }
+  const size_t pbytes = (size_t)prune_rows * c.d_hidden * 4;
+  const bool prelayout = relayout || pbytes > m->Cprune.bytes;
+  HIP_TRY(need(m->Cprune, pbytes));
+  if (prelayout && m->Cprune.p) HIP_TRY(hipMemsetAsync(m->Cprune.p, 0, m->Cprune.bytes, s));
+  if (m->plan_s_final > 1) HIP_TRY(need(m->X2, ((size_t)B * L / 2 + 256) * c.d_model * 4));
   if (pitch != m->conv_pitch) grew = true;  // the graphs bake the pitch in
   m->ws_prec = prec;
   m->conv_pitch = pitch;
@@ -264,36 +316,72 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   return ED_OK;
 }
 
-// The block stack: X (fp32 residual stream) is updated in place.  model.py:142-147 + ByteNetBlock.
-int run_blocks(ed_model* m, int B, int L, int prec, float* acts, hipStream_t s) {
+// The block stack (model.py:142-147 + ByteNetBlock).  The fp32 residual stream starts in X; unpruned layers update it
+// in place.  With `pruned` (OA-DM steps only) the trailing layers follow m->plan: they work on compact position sets
+// and a layer that narrows the set writes its output to the other of the two residual buffers.  *x_out receives the
+// buffer that holds the last block's output, L / m->plan_s_final rows per sequence when pruned.
+int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, const float** x_out, hipStream_t s) {
   const ed_config& c = m->cfg;
-  const int rows = B * L, D = c.d_model, H = c.d_hidden;
+  const int D = c.d_model, H = c.d_hidden, half = c.kernel_size / 2;
   const bool h = prec == ED_PREC_BF16;
+  const size_t esz = h ? 2 : 4;
   const int act = c.activation == 1 ? 1 : 2;
-  float* X = m->X.as<float>();
+  float* Xc = m->X.as<float>();
+  float* Xo = m->X2.as<float>();
   void* A = m->Abuf.p;
   void* Y = m->Ybuf.p;
-  void* Cp = m->Cpad.p;
   // GEMM1 / conv results feed a LayerNorm straight away; in the fast path they are stored as bf16 (the
   // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
   const bool y_bf16 = h;
   for (int i = 0; i < c.n_layers; ++i) {
     const LayerW& w = m->layers[i];
+    const LayerPlan pl = pruned ? m->plan[i] : LayerPlan{};
+    const int M_in = L / pl.s_in, M_out = L / pl.s_out, in_mul = pl.s_out / pl.s_in;
+    const int rows_in = B * M_in, rows_out = B * M_out;
     int rc;
-    // the 1x1 projections are row-independent: tile them over all B*L rows as one long sequence
-    if ((rc = run_ln(m, X, false, A, h, w.ln1_g, w.ln1_b, rows, D, L, L, 0, act, s))) return rc;
-    GemmProblem g1{A, rows, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows, H, D, 1, 1, h, y_bf16};
+    // the 1x1 projections are row-independent: tile them over all rows as one long sequence
+    if ((rc = run_ln(m, Xc, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+    GemmProblem g1{A, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
     if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
-    if ((rc = run_ln(m, Y, y_bf16, Cp, h, w.ln2_g, w.ln2_b, rows, H, L, m->conv_pitch, m->conv_row0, act, s))) return rc;
-    GemmProblem gc{Cp, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
-                   B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
-    if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
-    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows, H, L, L, 0, act, s))) return rc;
-    GemmProblem g2{A, rows, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, X, X, 1, rows, D, H, 1, 1, h, false};
+    long y_pitch;  // rows per sequence of the convolution result in Y
+    if (pl.s_in == 1) {
+      // every position: per-sequence zero halo in Cpad
+      const LnRowMap to_pad{L, L, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0};
+      if ((rc = run_ln(m, Y, y_bf16, m->Cpad.p, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
+      GemmProblem gc{m->Cpad.p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
+                     nullptr, B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
+      if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+      y_pitch = L;
+    } else {
+      // compact position set: neighbours at +-d are dc = d / s_in rows apart; the sequences sit back to back with
+      // `gap` zero rows between them and are convolved as ONE long sequence (the rows in the gaps are never read)
+      const int dc = w.dilation / pl.s_in;
+      const long gap = (long)half * dc, pitch = M_in + gap;
+      char* Cc = (char*)m->Cprune.p + (size_t)pl.cp_row * H * esz;
+      const LnRowMap to_compact{M_in, M_in, 0, 1, PosBit{}, pitch, gap};
+      if ((rc = run_ln(m, Y, y_bf16, Cc, h, w.ln2_g, w.ln2_b, rows_in, H, to_compact, act, s))) return rc;
+      GemmProblem gc{Cc, 0, gap, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
+                     1, (int)(B * pitch - gap), H, H, c.kernel_size, dc, h, y_bf16};
+      if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+      y_pitch = pitch;
+    }
+    // positions kept for the next layer: every in_mul-th row, starting at the row the fill position selects
+    PosBit sel;
+    if (in_mul > 1) sel = PosBit{m->order.as<int>(), m->state.as<StepState>(), __builtin_ctz(pl.s_in), in_mul - 1};
+    const LnRowMap keep{M_out, y_pitch, 0, in_mul, sel, M_out, 0};
+    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, keep, act, s))) return rc;
+    GemmProblem g2{A, rows_out, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, Xc, Xc, 1, rows_out, D, H, 1, 1, h, false};
+    if (in_mul > 1) {
+      g2.out = Xo;
+      g2.resid_mul = in_mul;
+      g2.resid_sel = sel;
+      std::swap(Xc, Xo);
+    }
     if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s))) return rc;
     if (acts)
-      HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows * D, X, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows_out * D, Xc, (size_t)rows_out * D * 4, hipMemcpyDeviceToDevice, s));
   }
+  if (x_out) *x_out = Xc;
   return ED_OK;
 }
 
@@ -324,13 +412,16 @@ int run_step(ed_model* m, int mode, int B, int L, int n, int prec, float* probs,
   const ed_config& c = m->cfg;
   int rc;
   if ((rc = run_embed(m, m->tok.as<int64_t>(), nullptr, B, L, s))) return rc;
-  if ((rc = run_blocks(m, B, L, prec, nullptr, s))) return rc;
+  const bool pruned = mode == MODE_OADM && m->plan_s_final > 1;
+  const float* xf = nullptr;
+  if ((rc = run_blocks(m, B, L, prec, nullptr, pruned, &xf, s))) return rc;
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
   if (mode == MODE_OADM) {
-    LAUNCH_TRY(launch_final_oadm(m->X.as<float>(), m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),
-                                 m->order.as<int>(), m->uni.as<float>(), m->state.as<StepState>(), probs, B, L,
-                                 c.d_model, n, s));
+    const int sf = pruned ? m->plan_s_final : 1;
+    LAUNCH_TRY(launch_final_oadm(xf, L / sf, __builtin_ctz(sf), m->last_g, m->last_b, m->dec_w, m->dec_b,
+                                 m->tok.as<int64_t>(), m->order.as<int>(), m->uni.as<float>(),
+                                 m->state.as<StepState>(), probs, B, L, c.d_model, n, s));
     LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * n * c.d_model, (double)B * c.d_model * 4.0));
   } else {
     const size_t kk = (size_t)c.timesteps * n * n;
@@ -560,7 +651,7 @@ int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* ti
   rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, s);
   if (!rc && acts_dev)
     HIP_TRY(hipMemcpyAsync(acts_dev, m->X.p, (size_t)B * L * m->cfg.d_model * 4, hipMemcpyDeviceToDevice, s));
-  if (!rc) rc = run_blocks(m, B, L, precision, acts_dev, s);
+  if (!rc) rc = run_blocks(m, B, L, precision, acts_dev, false, nullptr, s);
   if (!rc) {
     Probe pr(m, s);
     LAUNCH_TRY(pr.begin());
@@ -680,8 +771,27 @@ int ed_debug_ln_act(const void* in_dev, int in_bf16, void* out_dev, int out_bf16
                     const float* beta_dev, int rows, int C, int act, void* stream) {
   if (!in_dev || !out_dev || !gamma_dev || !beta_dev) return fail(ED_EINVAL, "null pointer");
   if (rows <= 0 || C <= 0 || C % 4 || C > 2048 || act < 0 || act > 2) return fail(ED_EINVAL, "bad LayerNorm shape");
-  LAUNCH_TRY(launch_ln_act(in_dev, in_bf16 != 0, out_dev, out_bf16 != 0, gamma_dev, beta_dev, rows, C, rows, rows, 0,
-                           act, (hipStream_t)stream));
+  LAUNCH_TRY(launch_ln_act(in_dev, in_bf16 != 0, out_dev, out_bf16 != 0, gamma_dev, beta_dev, rows, C,
+                           LnRowMap::plain(rows), act, (hipStream_t)stream));
+  return ED_OK;
+}
+
+int ed_model_set_option(ed_model* m, int option, int value) {
+  if (!m) return fail(ED_EINVAL, "null model handle");
+  switch (option) {
+    case ED_OPT_PRUNE:
+      if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_PRUNE takes 0 or 1");
+      m->prune = value != 0;
+      break;
+    case ED_OPT_MIN_TUNED_TILES:
+      if (value < 0) return fail(ED_EINVAL, "ED_OPT_MIN_TUNED_TILES must be >= 0");
+      m->min_tuned_tiles = value;
+      break;
+    default:
+      return fail(ED_EINVAL, "unknown option %d", option);
+  }
+  HIP_TRY(hipSetDevice(m->device));
+  m->drop_graphs();  // the captured launch sequences depend on both options
   return ED_OK;
 }
 

@@ -149,15 +149,17 @@ __device__ __forceinline__ void normalize_row(float (&v)[NCH][4], int C, int lan
 template <int NCH, bool IN_BF16, bool OUT_BF16>
 __global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int rows, int C, int L, long out_pitch, long out_row0, int act) {
+                                                     int rows, int C, LnRowMap map, int act) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const long seq = row / map.rows_per_seq, m = row - seq * map.rows_per_seq;
+  const long irow = map.in_row0 + seq * map.in_pitch + m * map.in_mul + map.in_sel.get();
   float v[NCH][4];
-  load_row<NCH, IN_BF16>(in, row, C, lane, v);
+  load_row<NCH, IN_BF16>(in, irow, C, lane, v);
   if constexpr (OUT_BF16) normalize_row_onepass<NCH>(v, C, lane);
   else normalize_row<NCH>(v, C, lane);
-  const long orow = (row / L) * out_pitch + out_row0 + (row % L);
+  const long orow = map.out_row0 + seq * map.out_pitch + m;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int idx = (c * 64 + lane) * 4;
@@ -243,12 +245,14 @@ __global__ __launch_bounds__(64) void final_oadm_kernel(const float* __restrict_
                                                         const float* beta, const float* dec_w, const float* dec_b,
                                                         int64_t* tokens, const int* __restrict__ order,
                                                         const float* __restrict__ uniforms, const StepState* state,
-                                                        float* probs, int B, int L, int D, int n_draw) {
+                                                        float* probs, int B, int L, int D, int n_draw,
+                                                        int x_rows_per_seq, int x_shift) {
   const int lane = threadIdx.x, b = blockIdx.x;
   const int step = state->step;
   const int pos = order[step];
   const long row = (long)b * L + pos;
-  const float logit = row_logits<NCH>(X, row, D, lane, gamma, beta, dec_w, dec_b, n_draw);
+  const long xrow = (long)b * x_rows_per_seq + (pos >> x_shift);
+  const float logit = row_logits<NCH>(X, xrow, D, lane, gamma, beta, dec_w, dec_b, n_draw);
   const float p = lane_softmax(logit, lane, n_draw);
   if (probs != nullptr && lane < n_draw) probs[((long)step * B + b) * n_draw + lane] = p;
   // inverse CDF: index = #{k : cdf[k] <= u * cdf[n-1]}, cdf = left-to-right fp32 running sum
@@ -343,23 +347,22 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
   } while (0)
 
 hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
-                         const float* beta, int rows, int C, int L, long out_pitch, long out_row0, int act,
-                         hipStream_t stream) {
+                         const float* beta, int rows, int C, const LnRowMap& map, int act, hipStream_t stream) {
   if (C % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
   const dim3 grid((rows + 3) / 4), block(256);
 #define ED_CALL(N)                                                                                            \
   if (in_bf16 && out_bf16)                                                                                    \
     hipLaunchKernelGGL((ln_act_kernel<N, true, true>), grid, block, 0, stream, in, out, gamma, beta, rows, C, \
-                       L, out_pitch, out_row0, act);                                                          \
+                       map, act);                                                          \
   else if (in_bf16)                                                                                           \
     hipLaunchKernelGGL((ln_act_kernel<N, true, false>), grid, block, 0, stream, in, out, gamma, beta, rows,   \
-                       C, L, out_pitch, out_row0, act);                                                       \
+                       C, map, act);                                                       \
   else if (out_bf16)                                                                                          \
     hipLaunchKernelGGL((ln_act_kernel<N, false, true>), grid, block, 0, stream, in, out, gamma, beta, rows,   \
-                       C, L, out_pitch, out_row0, act);                                                       \
+                       C, map, act);                                                       \
   else                                                                                                        \
-    hipLaunchKernelGGL((ln_act_kernel<N, false, false>), grid, block, 0, stream, in, out, gamma, beta, rows,  \
-                       C, L, out_pitch, out_row0, act)
+    hipLaunchKernelGGL((ln_act_kernel<N, false, false>), grid, block, 0, stream, in, out, gamma, beta, rows,   \
+                       C, map, act)
   ED_NCH_DISPATCH(C, ED_CALL);
 #undef ED_CALL
   return hipGetLastError();
@@ -377,15 +380,15 @@ hipError_t launch_final_logits(const float* X, const float* gamma, const float* 
   return hipGetLastError();
 }
 
-hipError_t launch_final_oadm(const float* X, const float* gamma, const float* beta, const float* dec_w,
-                             const float* dec_b, int64_t* tokens, const int* order, const float* uniforms,
-                             const StepState* state, float* probs, int B, int L, int D, int n_draw,
-                             hipStream_t stream) {
+hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
+                             const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
+                             const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
+                             int n_draw, hipStream_t stream) {
   if (D % 4 != 0 || n_draw > 64 || n_draw < 1 || B <= 0) return hipErrorInvalidValue;
   const dim3 grid(B), block(64);
 #define ED_CALL(N)                                                                                             \
   hipLaunchKernelGGL((final_oadm_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, tokens, order, \
-                     uniforms, state, probs, B, L, D, n_draw)
+                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift)
   ED_NCH_DISPATCH(D, ED_CALL);
 #undef ED_CALL
   return hipGetLastError();

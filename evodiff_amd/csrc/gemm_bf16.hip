@@ -119,6 +119,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   // (measured: the add-in-the-epilogue form made the x += PFF2(...) GEMM 2x slower than the same GEMM without it).
   const int fr = lane & 31, fh = lane >> 5;
   const bool full_rows = l0 + BM <= g.L;  // no row masking needed (always true when 256 | L)
+  const int rsel = RESID ? g.resid_sel.get() : 0;  // residual row of output row R: R * resid_mul + rsel
   f32x16 acc[2][NT];
   {
     const int nb = n0 + wc * (BN / 2) + fr;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
       for (int r = 0; r < 16; ++r) {
         const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         const bool on = full_rows || l < g.L;
-        const float* pr = RESID ? g.resid + ((long)b * g.L + l) * g.N + nb : nullptr;  // one address per row
+        const float* pr = RESID ? g.resid + (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + nb : nullptr;  // one address per row
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           float v = bias[j];
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
       constexpr int NG = (NVAL + VPG - 1) / VPG;          // groups: group g is loaded during step g-1, added in step g
       static_assert(NG <= RT, "K loop too short to hide the residual tile");
       // wave-uniform base + one 32-bit per-lane offset: the loads then need no per-element address registers
+      // (the launcher only picks this form for resid_mul == 1: residual row == output row)
       const float* rbase = g.resid + ((long)b * g.L + l0 + wr * 64) * g.N + n0 + wc * (BN / 2);
       const unsigned rlane = (unsigned)(4 * fh * g.N + fr);
       float rv[VPG];
@@ -272,7 +274,7 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   else if (p.ablate == 2) ED_GO(false, false, 2);
   else if (p.resid) {
     // hidden-residual form: 1x1, every tile full, K loop of a known length
-    const bool whole = !CONV && ((long)p.B * p.L) % BM == 0 && (p.B == 1 || p.L % BM == 0);
+    const bool whole = !CONV && ((long)p.B * p.L) % BM == 0 && (p.B == 1 || p.L % BM == 0) && p.resid_mul == 1;
     if (whole && p.K == 20 * BK)
       hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 20>), grid, block, 0, stream, p, tiles_n, tiles_total);
     else if (whole && NT == 4 && p.K == 8 * BK)

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     __syncthreads();
   }
 
+  const int rsel = RESID ? g.resid_sel.get() : 0;
   // epilogue: C[row][col] with col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
         if (l >= g.L) continue;
         const long o = ((long)b * g.L + l) * g.N + n;
         float v = acc[i][j][r] + bias;
-        if constexpr (RESID) v += g.resid[o];
+        if constexpr (RESID) v += g.resid[(((long)b * g.L + l) * g.resid_mul + rsel) * g.N + n];
         if constexpr (OUT_BF16) ((bf16_t*)g.out)[o] = f32_to_bf16_bits(v);
         else ((float*)g.out)[o] = v;
       }

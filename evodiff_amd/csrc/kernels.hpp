@@ -22,6 +22,17 @@ struct StepState {
   int t_start;  // D3PM: t of step 0; the current t is t_start - step
 };
 
+// Device-side selector: bits [shift, shift + log2(mask + 1)) of order[state->step], the position the current
+// OA-DM step fills (order == nullptr: always 0).  Lets row maps that depend on that position live inside a
+// captured graph.
+struct PosBit {
+  const int* order = nullptr;
+  const StepState* state = nullptr;
+  int shift = 0;
+  int mask = 0;
+  __device__ __forceinline__ int get() const { return order ? (order[state->step] >> shift) & mask : 0; }
+};
+
 // One implicit-GEMM problem: out[b*L + l][n] = bias[n] (+ resid) + sum_{tap,k} A[row(b, l + off(tap))][k] * W[tap][n][k]
 // with off(tap) = (tap - ntaps/2) * dilation and rows outside [0, L) contributing zero.
 struct GemmProblem {
@@ -35,6 +46,8 @@ struct GemmProblem {
   int B, L, N, K, ntaps, dilation;
   bool a_bf16;          // element type of A and W
   bool out_bf16;        // element type of out (resid != nullptr requires fp32 out)
+  int resid_mul = 1;    // the residual of output row R is row R * resid_mul + resid_sel.get() of `resid`
+  PosBit resid_sel;     //   (resid_mul > 1: every resid_mul-th row of a longer buffer; then resid must not alias out)
   int ablate = 0;       // diagnostic builds of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong)
 };
 
@@ -51,22 +64,31 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
                         const float* pe, int n_timesteps, const float* up_w, const float* up_b, float* X,
                         int rows, int B, int D, int E, int n_tokens, hipStream_t stream);
 
-// out = act(LayerNorm(in)) row-wise; in fp32/bf16 [rows][C]; out fp32/bf16, row r=(b,l) stored at
-// row b*out_pitch + out_row0 + l.  act: 0 none, 1 exact GELU, 2 ReLU.
+// Row maps of the LayerNorm kernel: logical row r = (b, m), m < rows_per_seq, is read from row
+// in_row0 + b*in_pitch + m*in_mul + in_sel.get() and written to row out_row0 + b*out_pitch + m.
+struct LnRowMap {
+  int rows_per_seq;
+  long in_pitch, in_row0;
+  int in_mul;
+  PosBit in_sel;
+  long out_pitch, out_row0;
+  static LnRowMap plain(int rows) { return LnRowMap{rows, rows, 0, 1, PosBit{}, rows, 0}; }
+};
+// out = act(LayerNorm(in)) row-wise; in, out fp32/bf16 rows of C channels.  act: 0 none, 1 exact GELU, 2 ReLU.
 hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
-                         const float* beta, int rows, int C, int L, long out_pitch, long out_row0, int act,
-                         hipStream_t stream);
+                         const float* beta, int rows, int C, const LnRowMap& map, int act, hipStream_t stream);
 
 // logits[r][k] = dec_b[k] + dec_w[k] . LayerNorm(X[r])  for all rows (ByteNetLMTime.forward tail).
 hipError_t launch_final_logits(const float* X, const float* gamma, const float* beta, const float* dec_w,
                                const float* dec_b, float* logits, int rows, int D, int n_tokens,
                                hipStream_t stream);
 
-// OA-DM step tail (generate.py:198-211): one categorical draw per sequence at position order[step].
-hipError_t launch_final_oadm(const float* X, const float* gamma, const float* beta, const float* dec_w,
-                             const float* dec_b, int64_t* tokens, const int* order, const float* uniforms,
-                             const StepState* state, float* probs, int B, int L, int D, int n_draw,
-                             hipStream_t stream);
+// OA-DM step tail (generate.py:198-211): one categorical draw per sequence at position pos = order[step].
+// X holds x_rows_per_seq rows per sequence; the row of position pos is pos >> x_shift.
+hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
+                             const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
+                             const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
+                             int n_draw, hipStream_t stream);
 
 // D3PM step tail (generate.py:279-298): softmax over K, fp64 posterior with Q[t] / Qbar[t-1], one draw per
 // position, in place on tokens.

@@ -125,6 +125,7 @@ class ByteNetLMTime(nn.Module):
         self.use_graph = os.environ.get("EVODIFF_AMD_GRAPH", "1") != "0"
         self._handle = None
         self._handle_key = None
+        self._options = {}
 
     # ------------------------------------------------------------------ device handle management
     def _weights_key(self, device_index):
@@ -152,6 +153,8 @@ class ByteNetLMTime(nn.Module):
                 host = value.detach().to("cpu", torch.float32).contiguous()
                 _lib.check(lib.ed_model_load_tensor(handle, name.encode(), host.data_ptr(), host.numel()))
             _lib.check(lib.ed_model_commit(handle))
+            for option, value in self._options.items():
+                _lib.check(lib.ed_model_set_option(handle, option, value))
         except Exception:
             lib.ed_model_destroy(handle)
             raise
@@ -252,6 +255,13 @@ class ByteNetLMTime(nn.Module):
                                           B, L, K, t_start, n_steps, post.data_ptr() if return_post else None,
                                           self._prec(), int(self.use_graph), stream))
         return post
+
+    def set_option(self, name, value):
+        """Execution options of the C ABI (include/evodiff_hip.h): "prune" (0/1), "min_tuned_tiles" (>= 0)."""
+        option = _lib.OPTIONS[name]
+        self._options[option] = int(value)
+        if self._handle is not None:
+            _lib.check(_lib.load().ed_model_set_option(self._handle, option, int(value)))
 
     def probe(self, every_n_steps):
         _lib.check(_lib.load().ed_probe_config(self.hip_handle(torch.device("cuda", torch.cuda.current_device())),

@@ -116,6 +116,16 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
                    const float* uniforms_dev, int B, int L, int K, int t_start, int n_steps,
                    double* post_dev, int precision, int use_graph, void* stream);
 
+/* Execution options (no counterpart in the reference; neither changes what is computed).
+ *   ED_OPT_PRUNE (default 1): ed_oadm_sample reads the network output at ONE position per step
+ *     (generate.py:198), so the trailing blocks whose dilations double from 1 are evaluated only on
+ *     the positions that output depends on ("dependency-cone pruning").  0 = every block
+ *     on every position.  ed_forward and ed_d3pm_sample always evaluate every position.
+ *   ED_OPT_MIN_TUNED_TILES (default 96): GEMMs with fewer 256-row tiles than this use the small-tile
+ *     kernel instead of the tuned one (0 = tuned kernel whenever the shape allows). */
+enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1 };
+int ed_model_set_option(ed_model* m, int option, int value);
+
 /* Measurement hooks (no counterpart in the reference).  With a probe interval n > 0, every n-th
  * sampling step (and every ed_forward) runs eagerly with a HIP-event pair around each kernel
  * launch on the caller's stream; ed_probe_read synchronises the stream, accumulates the event
