@@ -743,6 +743,15 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
   return ED_OK;
 }
 
+static long long* g_stamp_buf = nullptr;
+static int64_t g_stamp_cap = 0;
+
+int ed_debug_set_stamp_buffer(int64_t* stamps_dev, int64_t n) {
+  g_stamp_buf = (long long*)stamps_dev;
+  g_stamp_cap = stamps_dev ? n : 0;
+  return ED_OK;
+}
+
 int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const void* W_dev, const float* bias_dev,
                   void* out_dev, const float* resid_dev, int B, int L, int N, int K, int ntaps, int dilation,
                   int a_bf16, int out_bf16, int kernel, void* stream) {
@@ -757,6 +766,11 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   if (kernel >= 3) {  // diagnostic ablations of the tuned kernel (3: no MFMAs, 4: no DMA); results are not valid
     p.ablate = kernel - 2;
     kernel = 2;
+    if (p.ablate == 7) {  // in-kernel clock stamps: four values per 256-row tile
+      const int64_t tiles = (int64_t)B * ((L + 255) / 256) * ((N + 255) / 256);
+      if (!g_stamp_buf || g_stamp_cap < 4 * tiles) return fail(ED_EINVAL, "stamp buffer missing or too small");
+      p.stamps = g_stamp_buf;
+    }
   }
   if (kernel == 2 || (kernel == 0 && gemm_bf16_supported(p))) {
     if (!gemm_bf16_supported(p)) return fail(ED_EINVAL, "shape outside the tuned bf16 kernel's contract");

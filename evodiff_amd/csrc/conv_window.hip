@@ -1,0 +1,266 @@
+// Dilated k=5 convolution of the ByteNet block with the activation window kept in LDS (gfx950, bf16).
+//
+// gemm_bf16.hip treats the convolution as a GEMM over (tap, 64-channel slice) steps and copies the 256 activation
+// rows of every step from L2 again although the five taps of a slice read almost the same rows: rows
+// [l0 - 2d, l0 + 256 + 2d) shifted by 0, d, .. 4d.  With 576 rows to copy per step the LDS-DMA path (one 1-KiB
+// copy instruction per ~40 cycles per CU) is busy longer than the matrix pipe (2880 vs 2560 cycles per step), so
+// the waves queue on it.  Here the K loop runs slice-major: the WINDOW of 256 + 4d rows of a 64-channel slice is
+// copied once (spread over the five tap steps of the previous slice, one copy per wave per step) and each tap step
+// only brings in its 320 (256) weight rows.  Copies per step and wave drop from 9 to 6 (5 with N-tile 256), the
+// copy path is then shorter than the MFMA path, and the A fragments of tap t are simply read t*d rows further down
+// the window.  Same tile shape, swizzle and pinned issue order as gemm_bf16.hip.
+//
+// MFMA shape.  The loop is paced by the matrix pipe (~86 % busy in cycles) and the chip answers by lowering its
+// clock: measured with in-kernel stamps (ed_debug_gemm kernel 9), the 32x32x16 form of this loop ran at
+// 1.64-1.74 GHz, the same FLOPs issued as 16x16x32 MFMAs at 1.96-2.00 GHz at equal cycles (-11 % loop time).
+// Hence v_mfma_f32_16x16x32_bf16, with the weights as the row operand so that a lane ends up with four consecutive
+// output channels of one position (8/16-byte stores in the epilogue).
+//
+// LDS: 2 windows x 320 rows x 128 B + 2 weight stages x BN rows x 128 B = 160 KiB at BN = 320: the window is
+// limited to 320 rows, i.e. dilation <= 16 (five of the eight dilations of a ByteNet cycle).
+#include "kernels.hpp"
+
+#include <type_traits>
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int BM = 256, BK = 64, ROW_B = BK * 2;
+constexpr int WIN_ROWS = 320, WIN_BYTES = WIN_ROWS * ROW_B;
+constexpr int NTAPS = 5;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// STAMP: diagnostic build that also records the K loop's duration (GemmProblem::stamps).
+template <int NT, bool OUT_BF16, bool STAMP = false>
+__global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total, int win_groups) {
+  constexpr int BN = NT * 64;
+  constexpr int W_BYTES = BN * ROW_B;
+  constexpr int NGB = BN / 64;     // 8-row copy groups of the weight tile per wave and step
+  constexpr int NJ = 2 * NT;       // 16-column output tiles per wave
+  constexpr int NGRP = 2 * NJ;     // (32-channel k-slice, column tile) groups of 4 MFMAs per step
+  constexpr int RING = 4;          // weight fragments in flight
+  static_assert(NGRP % RING == 0, "the fragment ring must line up across steps");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * WIN_BYTES + 2 * W_BYTES];
+  char* const lds_w = lds + 2 * WIN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+
+  // XCD-aware tile order (as gemm_bf16.hip)
+  int tile;
+  {
+    const int id = blockIdx.x, q = tiles_total >> 3, r = tiles_total & 7, x = id & 7;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const int tiles_per_seq = (g.L + BM - 1) / BM;
+  const int b = tile_m / tiles_per_seq;
+  const int l0 = (tile_m - b * tiles_per_seq) * BM;
+  const int n0 = tile_n * BN;
+  const int ksteps = g.K / BK, d = g.dilation;
+
+  // ---- copy addressing: lane -> (row in 8-row group, physical 16-B chunk); logical chunk = physical ^ swizzle,
+  // swizzle of window / tile row p = (p >> 1) & 7 = 4 * (group parity) + (lane >> 4)
+  const long row_bytes = (long)g.K * 2;
+  const unsigned lane_row = (unsigned)((lane >> 3) * row_bytes);
+  const unsigned lane_off0 = lane_row + (((lane & 7) ^ (lane >> 4)) << 4);
+  const unsigned lane_off1 = lane_row + (((lane & 7) ^ (4 + (lane >> 4))) << 4);
+  const unsigned grp_bytes = (unsigned)(8 * row_bytes);
+  // window row 0 = position l0 - 2d of sequence b
+  const char* a_next = (const char*)g.A + ((long)b * g.a_seq_pitch + g.a_row0 + l0 - 2L * d) * row_bytes;
+  const char* w_dma = (const char*)g.W + (long)n0 * row_bytes;  // tap 0, slice 0, first channel of the tile
+  const unsigned w_lane_extra = (unsigned)((lane >> 5) * 4 * row_bytes);  // permuted rows: group row k reads channel + 4*(k >> 2)
+  const long w_tap_step = (long)g.N * row_bytes;
+  const long w_wrap_step = ROW_B - (long)(NTAPS - 1) * g.N * row_bytes;
+
+  auto copy_window_group = [&](int ga_raw, char* win) {  // groups past the window re-copy its last one
+    const int ga = ga_raw < win_groups ? ga_raw : win_groups - 1;
+    glds16(a_next + (unsigned)ga * grp_bytes + ((ga & 1) ? lane_off1 : lane_off0), win + ga * 1024);
+  };
+  auto copy_weight_group = [&](int jj, char* wst) {
+    const int grp = wid * NGB + jj;  // LDS rows 8*grp .. +7 <- channels c0 + {0..3, 8..11}
+    const int c0 = 32 * (grp >> 2) + 16 * (grp & 1) + 4 * ((grp >> 1) & 1);
+    glds16(w_dma + (long)c0 * row_bytes + (((grp & 1) ? lane_off1 : lane_off0) + w_lane_extra), wst + grp * 1024);
+  };
+
+  // ---- MFMA 16x16x32 with the WEIGHTS as the row operand: D[n][pos], lane (fr, fq) holds columns pos = fr of
+  // rows n = 4*fq .. 4*fq+3 of a 16 x 16 tile.
+  // Accumulators start at the bias: the epilogue is a pure store.
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool full_rows = l0 + BM <= g.L;
+  // The weight tile sits in LDS with its rows permuted (by the copy's source addresses): LDS row 32J + 16t + i holds
+  // channel 32J + 8*(i >> 2) + 4t + (i & 3), so that column tiles 2J and 2J+1 together give a lane EIGHT consecutive
+  // channels, 32J + 8*fq + 0..7: one 16-byte store per pair for bf16 outputs (the store tail is issue-bound).
+  const int nb = n0 + wc * (BN / 2) + 8 * fq;  // this lane's first channel
+  f32x4 acc[NJ][4];
+#pragma unroll
+  for (int jn = 0; jn < NJ; ++jn) {
+    const f32x4 bj = *(const f32x4*)(g.bias + nb + 32 * (jn >> 1) + 4 * (jn & 1));
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) acc[jn][ip] = bj;
+  }
+
+  // ---- fragment addressing: 16 rows x 32 channels per fragment, lane = (row fr, 8-channel chunk fq)
+  const int b_rd = (wc * (BN / 2) + fr) * ROW_B;
+  const int b_x = (fq ^ ((fr >> 1) & 7)) << 4;
+  const int a_row = wr * 64 + fr;  // window row of this lane's first activation fragment at tap 0
+  bf16x8 fact[2][4], fw[RING];
+
+  // prologue: window of slice 0 and weights of step 0
+  {
+#pragma unroll
+    for (int k = 0; k < WIN_ROWS / 64; ++k) copy_window_group(k * 8 + wid, lds);
+#pragma unroll
+    for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, lds_w);
+    w_dma += w_tap_step;
+    a_next += ksteps > 1 ? ROW_B : 0;
+    __syncthreads();
+  }
+
+  // One step = tap TAP of one 64-channel slice: 2 k-slices of 32 x NJ column tiles x 4 position tiles = 8*NJ MFMAs.
+  // The issue order is pinned; behind each MFMA comes at most one auxiliary instruction: the read of the weight
+  // fragment three groups ahead, a read of the second k-slice's activation fragments, or one of the step's copies.
+  auto step = [&](auto tap_c, const char* win, char* win_next, const char* wst, char* wst_next) {
+    constexpr int TAP = decltype(tap_c)::value;
+    const int shift = TAP * d;  // window rows between tap 0 and this tap
+    const char* a_base = win + (a_row + shift) * ROW_B;
+    const int a_x = (fq ^ (((fr + shift) >> 1) & 7)) << 4;  // chunk of k-slice s: (s << 6) ^ a_x
+    const char* b_base = wst + b_rd;
+    auto read_act = [&](int s2, int ip) { fact[s2][ip] = *(const bf16x8*)(a_base + ip * 16 * ROW_B + ((s2 << 6) ^ a_x)); };
+    auto read_w = [&](int grp) {
+      const int s2 = grp / NJ, jn = grp - s2 * NJ;
+      fw[grp % RING] = *(const bf16x8*)(b_base + jn * 16 * ROW_B + ((s2 << 6) ^ b_x));
+    };
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) read_act(0, ip);
+#pragma unroll
+    for (int grp = 0; grp < RING - 1; ++grp) read_w(grp);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+      const int s2 = grp / NJ, jn = grp - s2 * NJ;
+#pragma unroll
+      for (int ip = 0; ip < 4; ++ip) {
+        acc[jn][ip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[grp % RING], fact[s2][ip], acc[jn][ip], 0, 0, 0);
+        if (ip == 0) {
+          if (grp + RING - 1 < NGRP) read_w(grp + RING - 1);
+        } else if (ip == 1) {
+          if (grp >= 1 && grp <= 4) read_act(1, grp - 1);
+        } else if (ip == 2) {
+          if (grp >= 1 && grp <= NGB) copy_weight_group(grp - 1, wst_next);
+          else if (grp == NGB + 1) copy_window_group(TAP * 8 + wid, win_next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  const int T = ksteps * NTAPS;
+  int t = 0;  // global step index
+  unsigned long long c0 = 0, r0 = 0;
+  if constexpr (STAMP) {
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  for (int kc = 0; kc < ksteps; ++kc) {
+    const char* win = lds + (kc & 1) * WIN_BYTES;
+    char* win_next = lds + ((kc + 1) & 1) * WIN_BYTES;
+#define ED_TAP_STEP(TAPV)                                                                            \
+    {                                                                                                \
+      step(std::integral_constant<int, TAPV>{}, win, win_next, lds_w + (t & 1) * W_BYTES,            \
+           lds_w + ((t + 1) & 1) * W_BYTES);                                                         \
+      ++t;                                                                                           \
+      /* weights of step t+1: next tap, or tap 0 of the next slice; past the end the stream stalls */ \
+      w_dma += t + 1 < T ? (TAPV == NTAPS - 2 ? w_wrap_step : w_tap_step) : 0L;                      \
+      __syncthreads(); /* copies of this step landed (the fence drains them); stages free */         \
+    }
+    ED_TAP_STEP(0)
+    ED_TAP_STEP(1)
+    ED_TAP_STEP(2)
+    ED_TAP_STEP(3)
+    ED_TAP_STEP(4)
+#undef ED_TAP_STEP
+    a_next += kc + 2 < ksteps ? ROW_B : 0;
+  }
+  if constexpr (STAMP) {  // diagnostic build only: loop duration in shader cycles and in 100-MHz ticks
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      g.stamps[4 * tile] = 0;
+      g.stamps[4 * tile + 1] = (long long)(c1 - c0);
+      g.stamps[4 * tile + 2] = 0;
+      g.stamps[4 * tile + 3] = (long long)(r1 - r0);
+    }
+  }
+
+  // ---- epilogue: four consecutive channels of one position per lane and accumulator.  The row base is laundered
+  // through an empty asm so that the addresses are computed here and not kept live across the K loop.
+  int l0e = l0;
+  asm volatile("" : "+s"(l0e));
+#pragma unroll
+  for (int ip = 0; ip < 4; ++ip) {
+    const int l = l0e + wr * 64 + ip * 16 + fr;
+    if (full_rows || l < g.L) {
+      const long o = ((long)b * g.L + l) * g.N + nb;
+#pragma unroll
+      for (int jp = 0; jp < NT; ++jp) {  // column tiles 2jp, 2jp+1 hold channels nb + 32jp + 0..3, + 4..7
+        const f32x4 v = acc[2 * jp][ip], w = acc[2 * jp + 1][ip];
+        if constexpr (OUT_BF16) {
+          uint4 pk;
+          pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+          pk.z = (unsigned)f32_to_bf16_bits(w[0]) | ((unsigned)f32_to_bf16_bits(w[1]) << 16);
+          pk.w = (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16);
+          *(uint4*)((bf16_t*)g.out + o + 32 * jp) = pk;
+        } else {
+          *(f32x4*)((float*)g.out + o + 32 * jp) = v;
+          *(f32x4*)((float*)g.out + o + 32 * jp + 4) = w;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Shape contract (on top of gemm_bf16_supported): five taps, window of 256 + 4*dilation rows within 320, no
+// residual.  Memory contract: A rows [a_row0 - 2*dilation, a_row0 + ceil(L/256)*256 + 2*dilation + 8) of every
+// sequence are readable, and rows outside [0, L) hold zeros.
+bool conv_window_supported(const GemmProblem& p) {
+  if (!gemm_bf16_supported(p) || p.ntaps != NTAPS || p.resid) return false;
+  return BM + 4 * p.dilation <= WIN_ROWS;
+}
+
+hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream) {
+  if (!conv_window_supported(p)) return hipErrorInvalidValue;
+  const int win_groups = (BM + 4 * p.dilation + 7) / 8;
+  const dim3 block(512);
+#define ED_GO(NTV, OB)                                                                                   \
+  {                                                                                                      \
+    const int tiles_n = p.N / (NTV * 64);                                                                \
+    const int tiles_total = p.B * ((p.L + BM - 1) / BM) * tiles_n;                                       \
+    if (p.ablate == 7 && p.stamps)                                                                       \
+      hipLaunchKernelGGL((conv_window_kernel<NTV, OB, true>), dim3(tiles_total), block, 0, stream, p,    \
+                         tiles_n, tiles_total, win_groups);                                              \
+    else                                                                                                 \
+      hipLaunchKernelGGL((conv_window_kernel<NTV, OB>), dim3(tiles_total), block, 0, stream, p, tiles_n, \
+                         tiles_total, win_groups);                                                       \
+  }
+  if (p.N % 320 == 0) {
+    if (p.out_bf16) ED_GO(5, true) else ED_GO(5, false)
+  } else {
+    if (p.out_bf16) ED_GO(4, true) else ED_GO(4, false)
+  }
+#undef ED_GO
+  return hipGetLastError();
+}
+
+}  // namespace ed

@@ -3,7 +3,7 @@
 //   out[b*L + l][n] = bias[n] (+ resid) + sum_{tap, k} A[b, l + (tap - ntaps/2)*dilation][k] * W[tap][n][k]
 //
 // Tiling.  One 512-thread workgroup (8 waves = 4 (M) x 2 (N)) owns a 256 x BN output tile, BN = 320 or 256:
-// each wave a 64 x BN/2 sub-tile as 2 x NT MFMA 32x32x16 bf16 tiles (NT = 5 or 4; 160 / 128 fp32
+// each wave a 64 x BN/2 sub-tile as 4 x 2*NT MFMA 16x16x32 bf16 tiles (NT = 5 or 4; 160 / 128 fp32
 // accumulators per lane).  640M has N = 1280 = 4 x 320 and config 2 has 64 row tiles, i.e. exactly one
 // tile per CU of the 256-CU chip with no tail; N = 512 / 1024 (38M) use BN = 256.
 //
@@ -11,9 +11,9 @@
 // bytes = whole cache lines) are copied global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile
 // rows per wave-instruction) into one of two LDS stages, the copy of step t+1 in flight while step t is
 // multiplied; one barrier per step.  The issue order inside a step is pinned (sched_barrier after every
-// MFMA): behind each of the 40 (32) MFMAs of a step comes exactly one auxiliary instruction - one of the
-// 7 (6) fragment reads of the NEXT k-slice or one of the step's 9 (8) DMA copies - so neither the LDS read
-// latency nor the ~50-100-cycle issue cost of a copy ever opens an MFMA-free stretch in a wave.  (Left to
+// MFMA): behind each of the 80 (64) MFMAs of a step comes at most one auxiliary instruction - a fragment
+// read for a later MFMA group or one of the step's 9 (8) DMA copies - so neither the LDS read latency nor
+// the ~50-100-cycle issue cost of a copy ever opens an MFMA-free stretch in a wave.  (Left to
 // itself hipcc batches: all copies at the top of the step, then reads, a full wait, then MFMAs; with the two
 // waves of a SIMD in lockstep behind the same barrier that left the matrix pipe idle 45 % of the time.)
 //
@@ -31,7 +31,7 @@
 namespace ed {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
@@ -42,7 +42,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// ABLATE (diagnostic builds, results invalid): 1 = no MFMAs, 2 = no DMA copies.
+// ABLATE (diagnostic builds): 1 = no MFMAs, 2 = no DMA copies (results invalid); 3 = in-kernel clock stamps.
 // RT > 0 (1x1 + residual only): the K loop has exactly RT steps and is fully unrolled, and the residual tile is
 // streamed in DURING the loop (see below) instead of before it.
 template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0>
@@ -51,12 +51,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
   constexpr int NGB = BN / 64;      // 8-row DMA groups of the W tile per wave (A: 4 per wave)
   constexpr int N_DMA = 4 + NGB;    // copies per wave per step
-  constexpr int N_RD = NT + 2;      // fragment reads per k-slice
+  constexpr int NJ = 2 * NT;        // 16-column output tiles per wave
+  constexpr int NGRP = 2 * NJ;      // (32-channel k-slice, column tile) groups of 4 MFMAs per step
+  constexpr int RING = 4;           // weight fragments in flight
+  static_assert(NGRP % RING == 0 && N_DMA < NGRP, "step schedule");
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
+  unsigned long long sc0 = 0, sc1 = 0, sr0 = 0;
+  if constexpr (ABLATE == 3) {
+    sc0 = __builtin_amdgcn_s_memtime();
+    sr0 = __builtin_amdgcn_s_memrealtime();
+  }
 
   // XCD-aware tile order: workgroups id, id+8, ... share an XCD (and its L2); give each XCD a compact
   // block of the tile grid so that the tiles resident on it share A row panels and W column panels.
@@ -88,7 +96,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   const char* a_dma = (const char*)g.A +
                       ((long)b * g.a_seq_pitch + g.a_row0 + l0 + (long)(tap_lo - half_taps) * g.dilation + wid * 32) *
                           row_bytes;
-  const char* w_dma = (const char*)g.W + ((long)tap_lo * g.N + n0 + wid * (NGB * 8)) * row_bytes;
+  const char* w_dma = (const char*)g.W + ((long)tap_lo * g.N + n0) * row_bytes;
+  const unsigned w_lane_extra = (unsigned)((lane >> 5) * 4 * row_bytes);  // permuted rows: group row k reads channel + 4*(k >> 2)
   const long a_tap_step = (long)(g.dilation - 1) * row_bytes + ROW_B, w_tap_step = (long)(g.N - 1) * row_bytes + ROW_B;
   int dma_kk = 0, dma_t = 0;
 
@@ -99,8 +108,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     if (j < 4) {  // A rows wid*32 + 8j .. +8   (group wid*4 + j, parity j & 1)
       glds16(a_dma + (unsigned)j * grp_bytes + ((j & 1) ? lane_off1 : lane_off0), st + (wid * 4 + j) * 1024);
     } else {      // W rows n0 + 8*(wid*NGB + jj) .. +8
-      const int jj = j - 4, grp = wid * NGB + jj;
-      glds16(w_dma + (unsigned)jj * grp_bytes + ((grp & 1) ? lane_off1 : lane_off0), st + A_BYTES + grp * 1024);
+      const int jj = j - 4, grp = wid * NGB + jj;  // LDS rows 8*grp .. +7 <- channels c0 + {0..3, 8..11} (see below)
+      const int c0 = 32 * (grp >> 2) + 16 * (grp & 1) + 4 * ((grp >> 1) & 1);
+      glds16(w_dma + (long)c0 * row_bytes + (((grp & 1) ? lane_off1 : lane_off0) + w_lane_extra), st + A_BYTES + grp * 1024);
     }
   };
   // Advance the copy stream to the next step (branch-free).  Past the last step it stalls on the last tile:
@@ -114,56 +124,44 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     w_dma += more ? (wrap ? w_tap_step : (long)ROW_B) : 0L;
   };
 
+  // ---- MFMA 16x16x32 with the WEIGHTS as the row operand: D[n][pos]; lane (fr, fq) holds, per accumulator, the
+  // four consecutive output channels n = 4*fq .. 4*fq+3 of position fr of a 16 x 16 tile (shape choice: see
+  // conv_window.hip; the chip holds a higher clock on this shape than on 32x32x16).
   // Accumulators start at bias (+ residual): the epilogue is then a pure store, and the residual tile is
   // fetched here, where its latency hides behind the first DMA wait, instead of serialising the store tail
   // (measured: the add-in-the-epilogue form made the x += PFF2(...) GEMM 2x slower than the same GEMM without it).
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fr = lane & 15, fq = lane >> 4;
   const bool full_rows = l0 + BM <= g.L;  // no row masking needed (always true when 256 | L)
   const int rsel = RESID ? g.resid_sel.get() : 0;  // residual row of output row R: R * resid_mul + rsel
-  f32x16 acc[2][NT];
-  {
-    const int nb = n0 + wc * (BN / 2) + fr;
-    float bias[NT];
+  // The weight tile sits in LDS with its rows permuted (by the copy's source addresses): LDS row 32J + 16t + i holds
+  // channel 32J + 8*(i >> 2) + 4t + (i & 3), so that column tiles 2J and 2J+1 together give a lane EIGHT consecutive
+  // channels, 32J + 8*fq + 0..7: one 16-byte store per pair for bf16 outputs (the store tail is issue-bound).
+  const int nb = n0 + wc * (BN / 2) + 8 * fq;      // this lane's first channel
+  f32x4 acc[NJ][4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bias[j] = g.bias[nb + j * 32];
+  for (int jn = 0; jn < NJ; ++jn) {
+    const f32x4 bj = *(const f32x4*)(g.bias + nb + 32 * (jn >> 1) + 4 * (jn & 1));
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int ip = 0; ip < 4; ++ip) acc[jn][ip] = bj;
+  }
+  if constexpr (RESID && RT == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const bool on = full_rows || l < g.L;
-        const float* pr = RESID ? g.resid + (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + nb : nullptr;  // one address per row
+    for (int ip = 0; ip < 4; ++ip) {
+      const int l = l0 + wr * 64 + ip * 16 + fr;
+      if (full_rows || l < g.L) {
+        const float* pr = g.resid + (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + nb;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          float v = bias[j];
-          if constexpr (RESID && RT == 0)
-            if (on) v += pr[j * 32];
-          acc[i][j][r] = v;
-        }
+        for (int jn = 0; jn < NJ; ++jn) acc[jn][ip] += *(const f32x4*)(pr + 32 * (jn >> 1) + 4 * (jn & 1));
       }
+    }
   }
 
-  // ---- fragment addressing (32x32x16: lane = (row fr, k-half fh) holds 8 consecutive k)
-  const int fsw = (lane >> 1) & 7;
+  // ---- fragment addressing: 16 rows x 32 channels per fragment, lane = (row fr, 8-channel chunk fq); the
+  // swizzle (row >> 1) & 7 only depends on fr because every fragment starts at a multiple of 16 rows
+  const int f_x = (fq ^ ((fr >> 1) & 7)) << 4;       // chunk of k-slice s2: (s2 << 6) ^ f_x
   const int a_rd = (wr * 64 + fr) * ROW_B;
   const int b_rd = A_BYTES + (wc * (BN / 2) + fr) * ROW_B;
-
-  bf16x8 fa[2][2], fb[2][NT];  // [k-slice parity][fragment]
-  // read r (0 .. N_RD-1) of k-slice ks: A rows 0-31 first (the first MFMAs need it), then W, A rows 32-63 last
-  auto read_piece = [&](const char* st, int ks, int r) {
-    const char* base = st + (((2 * ks + fh) ^ fsw) << 4);
-    if (r == 0) fa[ks & 1][0] = *(const bf16x8*)(base + a_rd);
-    else if (r <= NT) fb[ks & 1][r - 1] = *(const bf16x8*)(base + b_rd + (r - 1) * 32 * ROW_B);
-    else fa[ks & 1][1] = *(const bf16x8*)(base + a_rd + 32 * ROW_B);
-  };
-  auto mfma_piece = [&](int ks, int q) {  // MFMA q (0 .. 2*NT-1) of k-slice ks
-    const int i = q / NT, j = q - i * NT;
-    if constexpr (ABLATE == 1) {
-      asm volatile("" ::"v"(fa[ks & 1][i]), "v"(fb[ks & 1][j]));  // keep the fragment reads alive
-    } else {
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
-    }
-  };
+  bf16x8 fact[2][4], fw[RING];  // activation fragments [k-slice][position tile]; ring of weight fragments
 
   if (T > 0) {
     // prologue: copy of step 0
@@ -172,24 +170,39 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     dma_advance();
     __syncthreads();  // (its fence drains the DMA)
 
-    // One step: 4 k-slices x 2*NT MFMAs; behind each MFMA one auxiliary instruction: first the reads of the
-    // next slice, then (slots left over) the copies of step t+1 into the other stage.
+    // One step: 2 k-slices of 32 x NJ column tiles x 4 position tiles = 8*NJ MFMAs in (k-slice, column tile) groups
+    // of 4.  The issue order is pinned; behind each MFMA comes at most one auxiliary instruction: the read of the
+    // weight fragment three groups ahead, a read of the second k-slice's activation fragments, or one of the
+    // step's copies into the other stage.
+    if constexpr (ABLATE == 3) sc1 = __builtin_amdgcn_s_memtime();
     auto step = [&](int t) {
       const char* st = lds + (t & 1) * STAGE;
+      auto read_act = [&](int s2, int ip) { fact[s2][ip] = *(const bf16x8*)(st + a_rd + ip * 16 * ROW_B + ((s2 << 6) ^ f_x)); };
+      auto read_w = [&](int grp) {
+        const int s2 = grp / NJ, jn = grp - s2 * NJ;
+        fw[grp % RING] = *(const bf16x8*)(st + b_rd + jn * 16 * ROW_B + ((s2 << 6) ^ f_x));
+      };
 #pragma unroll
-      for (int r = 0; r < N_RD; ++r) read_piece(st, 0, r);
+      for (int ip = 0; ip < 4; ++ip) read_act(0, ip);
+#pragma unroll
+      for (int grp = 0; grp < RING - 1; ++grp) read_w(grp);
       __builtin_amdgcn_sched_barrier(0);
-      int dma_j = 0;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int grp = 0; grp < NGRP; ++grp) {
+        const int s2 = grp / NJ, jn = grp - s2 * NJ;
 #pragma unroll
-        for (int q = 0; q < 2 * NT; ++q) {
-          mfma_piece(ks, q);
-          if (ks < 3 && q < N_RD) {
-            read_piece(st, ks + 1, q);
-          } else if (dma_j < N_DMA) {
-            dma_piece(dma_j);
-            ++dma_j;
+        for (int ip = 0; ip < 4; ++ip) {
+          if constexpr (ABLATE == 1) {
+            asm volatile("" ::"v"(fw[grp % RING]), "v"(fact[s2][ip]));  // keep the fragment reads alive
+          } else {
+            acc[jn][ip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[grp % RING], fact[s2][ip], acc[jn][ip], 0, 0, 0);
+          }
+          if (ip == 0) {
+            if (grp + RING - 1 < NGRP) read_w(grp + RING - 1);
+          } else if (ip == 1) {
+            if (grp >= 1 && grp <= 4) read_act(1, grp - 1);
+          } else if (ip == 2) {
+            if (grp >= 1 && grp <= N_DMA) dma_piece(grp - 1);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -201,24 +214,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     if constexpr (RESID && RT > 0) {
       // Residual tile hidden inside the K loop.  The x += PFF2(...) GEMM would otherwise read its 256 x BN fp32
       // tile either before the loop or in the epilogue, in both cases with every CU doing it at the same time
-      // and no MFMA running (measured: +40 us on a 60 us GEMM).  Here step t issues the loads of CPS accumulator
-      // tiles' worth of residual (16 dwords per lane each) right after the barrier, and step t+1 adds them into
-      // the accumulators before its first MFMA: the loads fly under a whole step of MFMAs and are retired by
-      // the step's own end-of-step wait.
-      constexpr int NVAL = 32 * NT;                       // residual values per lane
-      constexpr int VPG = ((NVAL + RT - 1) / RT + 7) & ~7;  // values per group (one group per step), 8 or 16
-      constexpr int NG = (NVAL + VPG - 1) / VPG;          // groups: group g is loaded during step g-1, added in step g
+      // and no MFMA running (measured: +40 us on a 60 us GEMM).  Here step t issues the loads of a few
+      // accumulators' worth of residual (one 16-byte load per accumulator) right after the barrier, and step t+1
+      // adds them into the accumulators before its first MFMA: the loads fly under a whole step of MFMAs and are
+      // retired by the step's own end-of-step wait.
+      constexpr int NACC = 4 * NJ;                          // accumulators (= 16-byte residual pieces) per lane
+      constexpr int APG = (NACC + RT - 1) / RT;             // pieces per group (one group per step)
+      constexpr int NG = (NACC + APG - 1) / APG;            // group g is loaded during step g-1, added in step g
       static_assert(NG <= RT, "K loop too short to hide the residual tile");
-      // wave-uniform base + one 32-bit per-lane offset: the loads then need no per-element address registers
+      // wave-uniform base + one 32-bit per-lane offset: the loads then need no per-piece address registers
       // (the launcher only picks this form for resid_mul == 1: residual row == output row)
       const float* rbase = g.resid + ((long)b * g.L + l0 + wr * 64) * g.N + n0 + wc * (BN / 2);
-      const unsigned rlane = (unsigned)(4 * fh * g.N + fr);
-      float rv[VPG];
+      const unsigned rlane = (unsigned)(fr * g.N + 8 * fq);
+      f32x4 rv[APG];
       auto load_group = [&](int grp) {
+        const float* rb = rbase;
+        asm volatile("" : "+s"(rb));  // addresses formed here, step by step, not hoisted out of the unrolled loop
 #pragma unroll
-        for (int v = 0; v < VPG; ++v) {
-          const int e = grp * VPG + v, c = e >> 4, r = e & 15;  // accumulator tile c = (i, j), register r
-          if (e < NVAL) rv[v] = (rbase + (long)((c / NT) * 32 + (r & 3) + 8 * (r >> 2)) * g.N + (c % NT) * 32)[rlane];
+        for (int v = 0; v < APG; ++v) {
+          const int e = grp * APG + v, jn = e >> 2, ip = e & 3;  // accumulator (jn, ip)
+          if (e < NACC) rv[v] = *(const f32x4*)(rb + (long)(ip * 16) * g.N + 32 * (jn >> 1) + 4 * (jn & 1) + rlane);
         }
       };
       load_group(0);
@@ -226,9 +241,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
       for (int t = 0; t < RT; ++t) {
         if (t < NG) {
 #pragma unroll
-          for (int v = 0; v < VPG; ++v) {
-            const int e = t * VPG + v, c = e >> 4, r = e & 15;
-            if (e < NVAL) acc[c / NT][c % NT][r] += rv[v];
+          for (int v = 0; v < APG; ++v) {
+            const int e = t * APG + v;
+            if (e < NACC) acc[e >> 2][e & 3] += rv[v];
           }
           if (t + 1 < NG) load_group(t + 1);
         }
@@ -239,27 +254,44 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
     }
   }
 
-  // ---- epilogue: C[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  // The row base is laundered through an empty asm so that the 32 row addresses are computed HERE: hoisted
-  // above the K loop as loop invariants (or shared with the residual loads) they cost 40-64 live registers.
+  unsigned long long sc2 = 0;
+  if constexpr (ABLATE == 3) sc2 = __builtin_amdgcn_s_memtime();
+  // ---- epilogue: four consecutive channels of one position per lane and accumulator.  The row base is laundered
+  // through an empty asm so that the addresses are computed HERE: hoisted above the K loop as loop invariants (or
+  // shared with the residual loads) they cost live registers.
   int l0e = l0;
   asm volatile("" : "+s"(l0e));
-  {
-    const int nb = n0 + wc * (BN / 2) + fr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int ip = 0; ip < 4; ++ip) {
+    const int l = l0e + wr * 64 + ip * 16 + fr;
+    if (full_rows || l < g.L) {
+      const long o = ((long)b * g.L + l) * g.N + nb;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int l = l0e + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (full_rows || l < g.L) {
-          const long o = ((long)b * g.L + l) * g.N + nb;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            if constexpr (OUT_BF16) ((bf16_t*)g.out)[o + j * 32] = f32_to_bf16_bits(acc[i][j][r]);
-            else ((float*)g.out)[o + j * 32] = acc[i][j][r];
-          }
+      for (int jp = 0; jp < NT; ++jp) {  // column tiles 2jp, 2jp+1 hold channels nb + 32jp + 0..3, + 4..7
+        const f32x4 v = acc[2 * jp][ip], w = acc[2 * jp + 1][ip];
+        if constexpr (OUT_BF16) {
+          uint4 pk;
+          pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+          pk.z = (unsigned)f32_to_bf16_bits(w[0]) | ((unsigned)f32_to_bf16_bits(w[1]) << 16);
+          pk.w = (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16);
+          *(uint4*)((bf16_t*)g.out + o + 32 * jp) = pk;
+        } else {
+          *(f32x4*)((float*)g.out + o + 32 * jp) = v;
+          *(f32x4*)((float*)g.out + o + 32 * jp + 4) = w;
         }
       }
+    }
+  }
+  if constexpr (ABLATE == 3) {  // diagnostic build: {prologue, K loop, epilogue incl. store drain} cycles, total ticks
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long sc3 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      g.stamps[4 * tile] = (long long)(sc1 - sc0);
+      g.stamps[4 * tile + 1] = (long long)(sc2 - sc1);
+      g.stamps[4 * tile + 2] = (long long)(sc3 - sc2);
+      g.stamps[4 * tile + 3] = (long long)(sr1 - sr0);
+    }
   }
 }
 
@@ -272,6 +304,12 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB>), grid, block, 0, stream, p, tiles_n, tiles_total)
   if (p.ablate == 1) ED_GO(false, false, 1);
   else if (p.ablate == 2) ED_GO(false, false, 2);
+  else if (p.ablate == 7 && p.stamps) {
+    if (p.resid && p.K == 20 * BK && p.resid_mul == 1 && !CONV)
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 3, 20>), grid, block, 0, stream, p, tiles_n, tiles_total);
+    else if (p.resid) ED_GO(false, true, 3);
+    else ED_GO(true, false, 3);
+  }
   else if (p.resid) {
     // hidden-residual form: 1x1, every tile full, K loop of a known length
     const bool whole = !CONV && ((long)p.B * p.L) % BM == 0 && (p.B == 1 || p.L % BM == 0) && p.resid_mul == 1;
@@ -304,6 +342,7 @@ bool gemm_bf16_supported(const GemmProblem& p) {
 
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream) {
   if (!gemm_bf16_supported(p)) return hipErrorInvalidValue;
+  if ((p.ablate == 0 || p.ablate >= 4) && conv_window_supported(p)) return launch_conv_window(p, stream);
   if (p.ntaps > 1) return p.N % 320 == 0 ? launch_nt<5, true>(p, stream) : launch_nt<4, true>(p, stream);
   return p.N % 320 == 0 ? launch_nt<5, false>(p, stream) : launch_nt<4, false>(p, stream);
 }

@@ -48,7 +48,8 @@ struct GemmProblem {
   bool out_bf16;        // element type of out (resid != nullptr requires fp32 out)
   int resid_mul = 1;    // the residual of output row R is row R * resid_mul + resid_sel.get() of `resid`
   PosBit resid_sel;     //   (resid_mul > 1: every resid_mul-th row of a longer buffer; then resid must not alias out)
-  int ablate = 0;       // diagnostic builds of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong)
+  long long* stamps = nullptr;  // diagnostics (ablate == 7): per tile {shader cycles, 100-MHz ticks} of the K loop
+  int ablate = 0;       // diagnostics of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong), 3 = no window form
 };
 
 // Reference-quality tile kernel: any shape with K % 32 == 0 (bf16) / K % 16 == 0 (fp32).
@@ -56,6 +57,10 @@ hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream);
 // Tuned bf16 kernel (see gemm_bf16.hip for its shape requirements); false = shape not supported.
 bool gemm_bf16_supported(const GemmProblem& p);
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream);
+// Window-in-LDS form of the dilated convolution (conv_window.hip): five taps, dilation <= 16; launch_gemm_bf16
+// picks it by itself when the shape allows (GemmProblem::ablate == 3 keeps the per-tap form, for comparisons).
+bool conv_window_supported(const GemmProblem& p);
+hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream);
 
 // tokens (B*L) int64 -> X fp32 [B*L][D]:  up_b + up_w @ (emb[tok] + pe[t])   (model.py:131-140)
 // tvec: int64 (B,) per-sequence timesteps with the reference's reshape quirk (row r uses tvec[r % B]),

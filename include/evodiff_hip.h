@@ -137,10 +137,16 @@ int ed_probe_read(ed_model* m, ed_probe_stat* stats, void* stream);
  *   out[b*L + l][n] = bias[n] (+ resid[b*L + l][n]) + sum_{tap,k} A[b*a_seq_pitch + a_row0 + l + (tap - ntaps/2)*dilation][k] * W[tap][n][k]
  * on caller-owned device buffers (A, W bf16 when a_bf16 != 0, else fp32; rows of A outside [0, L) of a
  * sequence must be readable and zero when ntaps > 1).  kernel: 0 = the library's own choice, 1 = generic
- * tile kernel, 2 = tuned bf16 kernel (fails with ED_EINVAL if the shape is outside its contract). */
+ * tile kernel, 2 = tuned bf16 kernel (fails with ED_EINVAL if the shape is outside its contract); 3 and above
+ * select diagnostic variants of the tuned kernels (tools/gemm_bench.py lists them). */
 int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const void* W_dev, const float* bias_dev,
                   void* out_dev, const float* resid_dev, int B, int L, int N, int K, int ntaps, int dilation,
                   int a_bf16, int out_bf16, int kernel, void* stream);
+
+/* Diagnostic hook for ed_debug_gemm(kernel = 9): a device buffer of n int64 that receives, per 256-row tile of the
+ * tuned kernels, {prologue, K loop, epilogue} shader cycles and the 100-MHz ticks they span (the windowed convolution
+ * stamps its K loop only: {0, loop cycles, 0, loop ticks}).  NULL detaches the buffer. */
+int ed_debug_set_stamp_buffer(int64_t* stamps_dev, int64_t n);
 
 /* Kernel-level test/benchmark hook (no counterpart in the reference): out = act(LayerNorm(in)) row-wise,
  * in/out fp32 or bf16 [rows][C], act 0 none / 1 exact-erf GELU / 2 ReLU. */

@@ -3,6 +3,8 @@
 
     python tools/gemm_bench.py [--B 64 --L 256 --N 1280 --K 1280 --taps 5 --dil 1 --kernel 0 --iters 50]
 
+--kernel: 0 library's choice, 1 generic, 2 tuned, 3 tuned without MFMAs, 4 tuned without copies, 5 per-tap form of
+the convolution, 6/7 other copy placements of the windowed convolution, 8 staggered copies, 9 in-kernel clock stamps.
 Random bf16 operands (uniform [-1, 1): zero-filled operands read high on MI355X), zero halo rows for the
 convolution, HIP-event timing over `iters` back-to-back launches.  Prints TFLOP/s on in-range taps only.
 """
@@ -28,7 +30,7 @@ def main():
     B, L = (1, a.B * a.L) if a.flat else (a.B, a.L)
     halo = (a.taps // 2) * a.dil
     pitch = halo + ((L + 255) // 256) * 256 + halo
-    A = torch.zeros((B, pitch, a.K), dtype=torch.bfloat16, device=dev)
+    A = torch.zeros((B * pitch + 8, a.K), dtype=torch.bfloat16, device=dev)[:B * pitch].view(B, pitch, a.K)  # + over-read slack
     A[:, halo:halo + L] = (torch.rand((B, L, a.K), device=dev) * 2 - 1).to(torch.bfloat16)
     W = ((torch.rand((a.taps, a.N, a.K), device=dev) * 2 - 1) / (a.K ** 0.5)).to(torch.bfloat16)
     bias = torch.rand(a.N, device=dev)
@@ -41,6 +43,10 @@ def main():
                                      resid.data_ptr() if a.resid else None, B, L, a.N, a.K, a.taps, a.dil, 1,
                                      a.out_bf16, a.kernel, stream))
 
+    stamps = None
+    if a.kernel == 9:
+        stamps = torch.zeros(4 * B * ((L + 255) // 256) * ((a.N + 255) // 256), dtype=torch.int64, device=dev)
+        _lib.check(lib.ed_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()))
     for _ in range(5):
         launch()
     torch.cuda.synchronize()
@@ -55,6 +61,16 @@ def main():
     flops = 2.0 * B * rows * a.N * a.K
     print(f"B={B} L={L} N={a.N} K={a.K} taps={a.taps} dil={a.dil} kernel={a.kernel}: {ms * 1e3:.1f} us/launch, "
           f"{flops / ms / 1e9:.1f} TFLOP/s (in-range taps)")
+    if stamps is not None:
+        st = stamps.view(-1, 4).cpu().double()
+        st = st[st[:, 3] > 0]
+        clk = (st[:, :3].sum(1) / st[:, 3]).median().item() * 100.0
+        steps = a.taps * (a.K // 64)
+        med = st.median(0).values
+        print(f"stamps (median over {len(st)} tiles): prologue {med[0]:.0f}, K loop {med[1]:.0f} ({med[1] / steps:.0f} per "
+              f"step), epilogue {med[2]:.0f} shader cycles; in-kernel clock {clk:.0f} MHz; stamped span "
+              f"{med[3] / 100.0:.1f} us (max {st[:, 3].max().item() / 100.0:.1f})")
+        _lib.check(lib.ed_debug_set_stamp_buffer(None, 0))
     if a.check:
         ref = torch.zeros((B, L, a.N), dtype=torch.float32, device=dev)
         Af = A.float()
@@ -63,7 +79,7 @@ def main():
             ref += Af[:, halo + off:halo + off + L] @ W[t].float().t()
         ref = ref.reshape(B * L, a.N) + bias
         if a.resid:
-            pass  # resid aliasing is exercised by the model tests
+            ref += resid
         err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
         print("max rel err vs torch fp32:", err)
 
