@@ -4,6 +4,8 @@
 // statistics are reduced with cross-lane shuffles, nothing is staged through LDS except small tables.
 #include "kernels.hpp"
 
+#include <type_traits>
+
 namespace ed {
 namespace {
 
@@ -183,6 +185,137 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast-path LayerNorm + activation (bf16 out).  Three LayerNorms per block make this kernel a fifth of a step;
+// plain streaming kernels move its bytes in 13 us (bf16 in) / 18 us (fp32 in) at config-2 size, so everything
+// besides the traffic has to hide under that:
+//  - a wave walks RPW consecutive rows and issues the loads of the next row before it works on the current one;
+//  - gamma / beta stay in registers across the rows of a wave;
+//  - the two row sums go through DPP adds inside each 16-lane row and four readlanes across them (the generic
+//    shuffle goes through the LDS crossbar: 12 dependent round trips per row);
+//  - GELU as x * sigmoid(x * (a + b x^2 + c x^4)), fitted to the exact-erf GELU to 2.6e-5 absolute on the whole
+//    axis (|x| clamped to 9 inside the polynomial, where the sigmoid is saturated): 7 plain + 2 quarter-rate
+//    instructions per element, and bf16 rounding (2^-9 relative) of the result is two orders coarser.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_sigmoid_fit(float x) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float A = -1.59501577f * LOG2E, B = -7.40112924e-02f * LOG2E, C = 7.03033587e-04f * LOG2E;
+  const float xc = __builtin_amdgcn_fmed3f(x, -9.0f, 9.0f);
+  const float x2 = xc * xc;
+  const float w = xc * fmaf(x2, fmaf(x2, C, B), A);        // -x (a + b x^2 + c x^4) log2(e)
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
+}
+
+// sum over the 64 lanes, result in every lane (all lanes active)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  const int vi = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+template <int NCH, bool IN_BF16, int RPW>
+__global__ __launch_bounds__(256) void ln_act_fast_kernel(const void* __restrict__ in, bf16_t* __restrict__ out,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int rows, int C,
+                                                          LnRowMap map, int act) {
+  typedef typename std::conditional<IN_BF16, uint2, float4>::type raw_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const int row0 = wave * RPW;
+  if (row0 >= rows) return;
+  const int nrows = rows - row0 < RPW ? rows - row0 : RPW;
+  const unsigned rps = (unsigned)map.rows_per_seq;
+  const int sel = map.in_sel.get();
+
+  float4 gm[NCH], bt[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = (c * 64 + lane) * 4;
+    if (idx < C) {
+      gm[c] = *(const float4*)(gamma + idx);
+      bt[c] = *(const float4*)(beta + idx);
+    }
+  }
+  auto in_row = [&](int row) -> long {
+    const unsigned seq = (unsigned)row / rps, m = (unsigned)row - seq * rps;
+    return map.in_row0 + (long)seq * map.in_pitch + (long)m * map.in_mul + sel;
+  };
+  auto out_row = [&](int row) -> long {
+    const unsigned seq = (unsigned)row / rps, m = (unsigned)row - seq * rps;
+    return map.out_row0 + (long)seq * map.out_pitch + m;
+  };
+  auto load_raw = [&](long irow, raw_t (&raw)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = (c * 64 + lane) * 4;
+      if (idx < C) {
+        if constexpr (IN_BF16) raw[c] = *(const uint2*)((const bf16_t*)in + irow * C + idx);
+        else raw[c] = *(const float4*)((const float*)in + irow * C + idx);
+      }
+    }
+  };
+
+  raw_t cur[NCH], nxt[NCH];
+  load_raw(in_row(row0), cur);
+  const float inv = 1.0f / (float)C;
+  for (int i = 0; i < nrows; ++i) {
+    if (i + 1 < nrows) load_raw(in_row(row0 + i + 1), nxt);
+    float v[NCH][4];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = (c * 64 + lane) * 4;
+      if (idx < C) {
+        if constexpr (IN_BF16) {
+          v[c][0] = __uint_as_float(cur[c].x << 16);
+          v[c][1] = __uint_as_float(cur[c].x & 0xffff0000u);
+          v[c][2] = __uint_as_float(cur[c].y << 16);
+          v[c][3] = __uint_as_float(cur[c].y & 0xffff0000u);
+        } else {
+          v[c][0] = cur[c].x; v[c][1] = cur[c].y; v[c][2] = cur[c].z; v[c][3] = cur[c].w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s += v[c][j];
+          q = fmaf(v[c][j], v[c][j], q);
+        }
+      }
+    }
+    s = wave_sum_dpp(s);
+    q = wave_sum_dpp(q);
+    const float mean = s * inv;
+    const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + LN_EPS);
+    const float shift = -mean * rstd;
+    bf16_t* orow = out + out_row(row0 + i) * C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = (c * 64 + lane) * 4;
+      if (idx < C) {
+        const float g4[4] = {gm[c].x, gm[c].y, gm[c].z, gm[c].w}, b4[4] = {bt[c].x, bt[c].y, bt[c].z, bt[c].w};
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          y[j] = fmaf(fmaf(v[c][j], rstd, shift), g4[j], b4[j]);
+          if (act == 1) y[j] = gelu_sigmoid_fit(y[j]);
+          else if (act == 2) y[j] = fmaxf(y[j], 0.f);
+        }
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        const bf16x4 pk = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};  // v_cvt_pk_bf16_f32 (RNE)
+        *(bf16x4*)(orow + idx) = pk;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+  }
+}
+
 // last_norm + decoder for one row held by one wave: returns logit k in lane k (k < n_out <= 64).
 template <int NCH>
 __device__ __forceinline__ float row_logits(const float* X, long row, int D, int lane, const float* gamma,
@@ -349,6 +482,21 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
 hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
                          const float* beta, int rows, int C, const LnRowMap& map, int act, hipStream_t stream) {
   if (C % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
+  if (out_bf16) {
+    // one row per wave measured fastest (2/4/8 rows per wave with a register prefetch of the next row: +1..+7 us
+    // at config-2 size; 1-16 waves per block: no difference)
+    const dim3 fgrid((rows + 3) / 4), fblock(256);
+#define ED_FAST(N)                                                                                             \
+    if (in_bf16)                                                                                               \
+      hipLaunchKernelGGL((ln_act_fast_kernel<N, true, 1>), fgrid, fblock, 0, stream, in, (bf16_t*)out, gamma,  \
+                         beta, rows, C, map, act);                                                             \
+    else                                                                                                       \
+      hipLaunchKernelGGL((ln_act_fast_kernel<N, false, 1>), fgrid, fblock, 0, stream, in, (bf16_t*)out, gamma, \
+                         beta, rows, C, map, act)
+    ED_NCH_DISPATCH(C, ED_FAST);
+#undef ED_FAST
+    return hipGetLastError();
+  }
   const dim3 grid((rows + 3) / 4), block(256);
 #define ED_CALL(N)                                                                                            \
   if (in_bf16 && out_bf16)                                                                                    \
