@@ -96,6 +96,7 @@ struct ed_model {
   std::unordered_map<std::string, std::vector<float>> staged;
 
   DevBuf w32, w16;  // packed weight images
+  DevBuf emb_table; // timesteps == 0: the n_tokens possible embedded rows, fp32 [n_tokens][d_model]
   const float *emb = nullptr, *up_w = nullptr, *up_b = nullptr, *pe = nullptr;
   const float *last_g = nullptr, *last_b = nullptr, *dec_w = nullptr, *dec_b = nullptr;
   std::vector<LayerW> layers;
@@ -389,9 +390,11 @@ int run_embed(ed_model* m, const int64_t* tokens, const int64_t* tvec, int B, in
   const ed_config& c = m->cfg;
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
-  LAUNCH_TRY(launch_embed(tokens, tvec, m->state.as<StepState>(), m->emb, c.timesteps > 0 ? m->pe : nullptr,
-                          c.timesteps, m->up_w, m->up_b, m->X.as<float>(), B * L, B, c.d_model, c.d_embed,
-                          c.n_tokens, s));
+  if (c.timesteps == 0)
+    LAUNCH_TRY(launch_embed_gather(tokens, m->emb_table.as<float>(), m->X.as<float>(), B * L, c.d_model, c.n_tokens, s));
+  else
+    LAUNCH_TRY(launch_embed(tokens, tvec, m->state.as<StepState>(), m->emb, m->pe, c.timesteps, m->up_w, m->up_b,
+                            m->X.as<float>(), B * L, B, c.d_model, c.d_embed, c.n_tokens, s));
   LAUNCH_TRY(pr.end(ED_K_EMBED, 2.0 * B * L * c.d_embed * c.d_model, (double)B * L * (8 + c.d_model * 4.0)));
   return ED_OK;
 }
@@ -629,6 +632,18 @@ int ed_model_commit(ed_model* m) {
     m->layers[i] = LayerW{dil[i], b32 + o.ln1g, b32 + o.ln1b, b32 + o.b1, b32 + o.ln2g, b32 + o.ln2b, b32 + o.bc,
                           b32 + o.ln3g, b32 + o.ln3b, b32 + o.b2, b32 + o.w1, b32 + o.wc, b32 + o.w2,
                           b16 + o.w1h, b16 + o.wch, b16 + o.w2h};
+  }
+  if (c.timesteps == 0) {
+    // the embedded row of each token, computed by the embedding kernel itself (same arithmetic as a per-row call)
+    std::vector<int64_t> ids((size_t)c.n_tokens);
+    for (int i = 0; i < c.n_tokens; ++i) ids[i] = i;
+    DevBuf ids_dev;
+    HIP_TRY(ids_dev.ensure(ids.size() * 8));
+    HIP_TRY(m->emb_table.ensure((size_t)c.n_tokens * c.d_model * 4));
+    HIP_TRY(hipMemcpy(ids_dev.p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(launch_embed(ids_dev.as<int64_t>(), nullptr, nullptr, m->emb, nullptr, 0, m->up_w, m->up_b,
+                         m->emb_table.as<float>(), c.n_tokens, 1, c.d_model, c.d_embed, c.n_tokens, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
   }
   m->staged.clear();
   m->drop_graphs();

@@ -71,6 +71,21 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   }
 }
 
+// Models without timestep encoding: the embedded row only depends on the token, so the n_tokens possible rows are
+// computed once (by embed_kernel itself, at commit) and a step just copies them: one wave per row.
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ tokens,
+                                                           const float* __restrict__ table, float* __restrict__ X,
+                                                           int rows, int D, int n_tokens) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long tok = tokens[row];
+  if (tok < 0 || tok >= n_tokens) tok = n_tokens - 1;  // host validates; never index out of the table
+  const float4* src = (const float4*)(table + tok * D);
+  float4* dst = (float4*)(X + row * D);
+  for (int c = lane; c < D / 4; c += 64) dst[c] = src[c];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm (+ activation), one wave per row, NCH chunks of 256 channels held in registers.
 // ---------------------------------------------------------------------------------------------------
@@ -465,6 +480,14 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
   if (E > 16 || rows <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, stream, tokens, tvec, state, emb, pe, n_timesteps,
                      up_w, up_b, X, rows, B, D, E, n_tokens);
+  return hipGetLastError();
+}
+
+hipError_t launch_embed_gather(const int64_t* tokens, const float* table, float* X, int rows, int D, int n_tokens,
+                               hipStream_t stream) {
+  if (D % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, tokens, table, X, rows, D,
+                     n_tokens);
   return hipGetLastError();
 }
 

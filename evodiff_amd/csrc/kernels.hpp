@@ -69,6 +69,10 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
                         const float* pe, int n_timesteps, const float* up_w, const float* up_b, float* X,
                         int rows, int B, int D, int E, int n_tokens, hipStream_t stream);
 
+// X[r] = table[tokens[r]] for a table of n_tokens embedded rows (models without timestep encoding).
+hipError_t launch_embed_gather(const int64_t* tokens, const float* table, float* X, int rows, int D, int n_tokens,
+                               hipStream_t stream);
+
 // Row maps of the LayerNorm kernel: logical row r = (b, m), m < rows_per_seq, is read from row
 // in_row0 + b*in_pitch + m*in_mul + in_sel.get() and written to row out_row0 + b*out_pitch + m.
 struct LnRowMap {
