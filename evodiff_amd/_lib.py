@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libevodiff_hip.so")
+# $EVODIFF_AMD_LIB: another build of the same library (A/B comparisons of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("EVODIFF_AMD_LIB") or os.path.join(_HERE, "csrc", "libevodiff_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
 K_EMBED, K_LNACT, K_GEMM1X1, K_CONV, K_FINAL, K_COUNT = 0, 1, 2, 3, 4, 5

@@ -7,8 +7,8 @@
 // zero ('same' padding) and taps whose whole 128-row tile is outside are skipped.
 //
 // This is the correctness-first kernel: 128x128 output tile per 256-thread workgroup (4 waves, each
-// 64x64 as 2x2 MFMA 32x32 tiles), register-staged global->LDS copies with bounds checks, so it takes
-// any B, L, N and any K that is a multiple of one K-step.  It is the fp32 validation path
+// 64x64 as 2x2 MFMA 32x32 tiles), register-staged global->LDS copies (two K-steps ahead) with bounds checks, so
+// it takes any B, L, N and any K that is a multiple of 64 bytes.  It is the fp32 validation path
 // (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) and the fallback for bf16 shapes the tuned kernel
 // in gemm_bf16.hip does not cover.
 #include "kernels.hpp"
@@ -21,8 +21,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 namespace {
 
 constexpr int BM = 128, BN = 128;
-constexpr int ROW_BYTES = 64;    // bytes of K per tile row per K-step (16 fp32 / 32 bf16)
-constexpr int LDS_STRIDE = 80;   // 64 + 16 pad: the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
+constexpr int ROW_BYTES = 128;   // bytes of K per tile row per K-step (32 fp32 / 64 bf16)
+constexpr int LDS_STRIDE = 144;  // 128 + 16 pad: the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
 
 template <bool BF16, bool OUT_BF16, bool RESID>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   const int l0 = (blockIdx.y % tiles_per_seq) * BM;
   const int n0 = blockIdx.x * BN;
 
-  // loader role: thread -> (tile row, 32-byte half of the 64-byte K slice)
+  // loader role: thread -> (tile row, 64-byte half of the 128-byte K slice)
   const int lrow = tid >> 1, lhalf = tid & 1;
-  const int ksteps = g.K / KSTEP;
+  const int ksteps = (g.K + KSTEP - 1) / KSTEP;   // the last slice may be half full (K is a multiple of 64 bytes)
   const int half_taps = g.ntaps / 2;
+  const bool last_half_empty = (g.K % KSTEP) != 0;
 
   // contiguous range of taps that touch this tile at all
   int tap_lo = 0, tap_hi = g.ntaps - 1;
@@ -54,25 +55,30 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   const char* Wbase = (const char*)g.W;
   const int nrow = n0 + lrow;
 
-  uint4 ra0, ra1, rb0, rb1;
-  auto gload = [&](int it) {
+  // Two register sets: the loads of K-step it+2 are issued as soon as set (it & 1) has been written to LDS, so every
+  // load has two full steps to return (small problems run few workgroups per CU and are latency-bound otherwise).
+  uint4 ra[2][4], rb[2][4];
+  auto gload = [&](int it, uint4 (&a4)[4], uint4 (&b4)[4]) {
     const int tap = it / ksteps;
-    const int kk = (it - tap * ksteps) * KSTEP;
+    const int ks = it - tap * ksteps;
     const int l = l0 + lrow + (tap - half_taps) * g.dilation;
     const uint4 z = make_uint4(0, 0, 0, 0);
-    if (l >= 0 && l < g.L) {
-      const char* p = Abase + (((long)b * g.a_seq_pitch + g.a_row0 + l) * g.K + kk) * ESZ + lhalf * 32;
-      ra0 = *(const uint4*)p;
-      ra1 = *(const uint4*)(p + 16);
+    const bool k_on = !(last_half_empty && ks == ksteps - 1 && lhalf == 1);
+    if (k_on && l >= 0 && l < g.L) {
+      const uint4* p = (const uint4*)(Abase + (((long)b * g.a_seq_pitch + g.a_row0 + l) * g.K + (long)ks * KSTEP) * ESZ + lhalf * 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] = p[i];
     } else {
-      ra0 = z; ra1 = z;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] = z;
     }
-    if (nrow < g.N) {
-      const char* p = Wbase + (((long)tap * g.N + nrow) * g.K + kk) * ESZ + lhalf * 32;
-      rb0 = *(const uint4*)p;
-      rb1 = *(const uint4*)(p + 16);
+    if (k_on && nrow < g.N) {
+      const uint4* p = (const uint4*)(Wbase + (((long)tap * g.N + nrow) * g.K + (long)ks * KSTEP) * ESZ + lhalf * 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b4[i] = p[i];
     } else {
-      rb0 = z; rb1 = z;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b4[i] = z;
     }
   };
 
@@ -84,48 +90,58 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (it_begin < it_end) gload(it_begin);
   const int fr = lane & 31, fh = lane >> 5;
-  for (int it = it_begin; it < it_end; ++it) {
-    *(uint4*)(ldsA + lrow * LDS_STRIDE + lhalf * 32) = ra0;
-    *(uint4*)(ldsA + lrow * LDS_STRIDE + lhalf * 32 + 16) = ra1;
-    *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 32) = rb0;
-    *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 32 + 16) = rb1;
-    __syncthreads();
-    if (it + 1 < it_end) gload(it + 1);
-    // Each lane takes 32 contiguous bytes of its row at byte 32*fh.  The k order seen by the MFMA is a
-    // permutation of the true k, identical for A and B, so the sum over k is unchanged.
-    uint4 fa[2][2], fb[2][2];
+  auto step = [&](int it, uint4 (&a4)[4], uint4 (&b4)[4]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const char* pa = ldsA + (wr * 64 + i * 32 + fr) * LDS_STRIDE + fh * 32;
-      fa[i][0] = *(const uint4*)pa;
-      fa[i][1] = *(const uint4*)(pa + 16);
-      const char* pb = ldsB + (wc * 64 + i * 32 + fr) * LDS_STRIDE + fh * 32;
-      fb[i][0] = *(const uint4*)pb;
-      fb[i][1] = *(const uint4*)(pb + 16);
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(ldsA + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = a4[i];
+      *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = b4[i];
     }
+    __syncthreads();
+    if (it + 2 < it_end) gload(it + 2, a4, b4);
+    // Each lane takes 32 contiguous bytes of its row at byte 64*h + 32*fh of the slice.  The k order seen by the
+    // MFMA is a permutation of the true k, identical for A and B, so the sum over k is unchanged.
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int h = 0; h < 2; ++h) {
+      uint4 fa[2][2], fb[2][2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if constexpr (BF16) {
+      for (int i = 0; i < 2; ++i) {
+        const char* pa = ldsA + (wr * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
+        fa[i][0] = *(const uint4*)pa;
+        fa[i][1] = *(const uint4*)(pa + 16);
+        const char* pb = ldsB + (wc * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
+        fb[i][0] = *(const uint4*)pb;
+        fb[i][1] = *(const uint4*)(pb + 16);
+      }
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, fa[i][s]), __builtin_bit_cast(bf16x8, fb[j][s]), acc[i][j], 0, 0, 0);
-        } else {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const float* a4 = (const float*)&fa[i][s];
-            const float* b4 = (const float*)&fb[j][s];
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (BF16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc[i][j], 0, 0, 0);
+            for (int s = 0; s < 2; ++s)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, fa[i][s]), __builtin_bit_cast(bf16x8, fb[j][s]), acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const float* a4f = (const float*)&fa[i][s];
+              const float* b4f = (const float*)&fb[j][s];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4f[q], b4f[q], acc[i][j], 0, 0, 0);
+            }
           }
         }
-      }
+    }
     __syncthreads();
+  };
+
+  if (it_begin < it_end) gload(it_begin, ra[0], rb[0]);
+  if (it_begin + 1 < it_end) gload(it_begin + 1, ra[1], rb[1]);
+  for (int it = it_begin; it < it_end; it += 2) {
+    step(it, ra[0], rb[0]);
+    if (it + 1 < it_end) step(it + 1, ra[1], rb[1]);
   }
 
   const int rsel = RESID ? g.resid_sel.get() : 0;
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
 }  // namespace
 
 hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream) {
-  const int kstep = p.a_bf16 ? 32 : 16;
+  const int kstep = p.a_bf16 ? 32 : 16;  // 64 bytes: the unit the kernel masks the K tail in
   if (p.K % kstep != 0 || p.B <= 0 || p.L <= 0 || p.N <= 0 || (p.ntaps & 1) == 0) return hipErrorInvalidValue;
   if (p.resid && p.out_bf16) return hipErrorInvalidValue;
   dim3 grid((p.N + BN - 1) / BN, (unsigned)(p.B * ((p.L + BM - 1) / BM)));

@@ -1,12 +1,13 @@
 #!/bin/bash
-# conv and 1x1 GEMM at shrinking row counts, tuned (2) vs generic (1) kernel
-for rows in 64 32 16 8 4 2 1; do
-  for k in 1 2; do
-    timeout -k 10 60 python tools/gemm_bench.py --B $rows --L 256 --flat 1 --taps 5 --dil 1 --kernel $k --out_bf16 1 --iters 30 2>&1 | grep us/launch || exit 1
-  done
+# generic (1) vs tuned (2) kernel at shrinking row counts; correctness of the generic kernel on ragged shapes
+set -e
+g() { timeout -k 10 60 python tools/gemm_bench.py "$@" --check 1 2>&1 | grep -E "us/launch|rel err" | paste - -; }
+for rows in 16 8 4 2 1; do
+  g --B $rows --L 256 --flat 1 --taps 5 --dil 1 --kernel 1 --out_bf16 1 --iters 30
 done
-for rows in 64 32 16 8 4 2 1; do
-  for k in 1 2; do
-    timeout -k 10 60 python tools/gemm_bench.py --B $rows --L 256 --flat 1 --taps 1 --kernel $k --out_bf16 1 --iters 30 2>&1 | grep us/launch || exit 1
-  done
+for rows in 16 4 1; do
+  g --B $rows --L 256 --flat 1 --taps 1 --kernel 1 --out_bf16 1 --iters 30
+  g --B $rows --L 256 --flat 1 --taps 1 --kernel 1 --resid 1 --iters 30
 done
+g --B 3 --L 77 --N 96 --K 96 --taps 5 --dil 3 --kernel 1 --iters 3
+g --B 2 --L 130 --N 200 --K 160 --taps 1 --kernel 1 --resid 1 --iters 3
