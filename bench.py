@@ -9,10 +9,12 @@ L=256 (256 denoiser forwards + draws) on every rank, followed by the all-gather 
 N > 1.  Weights are synthetic (reference-constructor default init under seed 0), inputs are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel is the dilated-conv implicit GEMM.  Its launches are timed live with HIP-event
-pairs on the launch stream on every 32nd diffusion step inside the timed region; achieved = algorithmic FLOPs
-of those launches (in-range taps only) / their summed duration, against the 2.5 PFLOP/s dense
-bf16 MFMA peak.  cpu_baseline: the CPU oracle (a port of the reference's PyTorch path) timed on this host for
+roofline: the dominant kernel is the windowed dilated convolution (conv_window_kernel, dilation <= 16: 41 of a
+step's 340 launches, 28 % of its time).  Its launches are timed live with HIP-event pairs on the launch stream on
+every 32nd diffusion step inside the timed region; achieved = algorithmic FLOPs of those launches (in-range taps
+only) / their summed duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.  traffic = memory-side
+bytes of one such launch from the committed PMC passes (profiles/, tools/pmc_traffic.sh), for the default
+config only.  cpu_baseline: the CPU oracle (a port of the reference's PyTorch path) timed on this host for
 a bounded sample.
 """
 import argparse
@@ -50,6 +52,19 @@ def cpu_baseline(L, seconds_budget=20.0):
     return {"value": 1.0 / (per_step * L), "unit": "sequences/sec", "cores": threads, "kind": "port",
             "sample": f"oracle (fp32 PyTorch CPU) OA_DM_640M B=1 L={L}: {n} diffusion steps timed, "
                       f"{per_step:.3f} s/step, extrapolated to {L} steps per sequence"}
+
+
+def measured_traffic(args):
+    """Memory-side bytes per launch of the dominant kernel, from the committed PMC summary (None if the run's
+    configuration is not the one the counters were collected on)."""
+    path = os.path.join(ROOT, "profiles", "r01_conv_window_traffic.json")
+    if not (args.model == "640M" and args.batch == 64 and args.seq_len == 256 and args.precision == "bf16"):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -145,8 +160,9 @@ def main():
                                    f"{'off' if args.no_graph else 'on'}",
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world} (sequence sharding)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "kernel": "dilated-conv implicit GEMM", "launches_timed": conv["launches"],
+                         "frac": achieved / peak, "traffic": measured_traffic(args),
+                         "kernel": "conv_window_kernel (dilated k=5 convolution, dilation <= 16)",
+                         "launches_timed": conv["launches"],
                          "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
                          "flops_per_launch": conv["flops"] / max(conv["launches"], 1)},
             "kernel_ms_share": {k: v["ms"] for k, v in stats.items()},

@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVODIFF_AMD_LIB") or os.path.join(_HERE, "csrc", "libevodiff_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
-K_EMBED, K_LNACT, K_GEMM1X1, K_CONV, K_FINAL, K_COUNT = 0, 1, 2, 3, 4, 5
-KIND_NAMES = ("embed", "ln_act", "gemm1x1", "conv", "final")
+K_EMBED, K_LNACT, K_GEMM1X1, K_CONV, K_FINAL, K_CONV_OTHER, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+KIND_NAMES = ("embed", "ln_act", "gemm1x1", "conv", "final", "conv_other")
 OPTIONS = {"prune": 0, "min_tuned_tiles": 1}   # ED_OPT_* in include/evodiff_hip.h
 
 # every symbol include/evodiff_hip.h declares

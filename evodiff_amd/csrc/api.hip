@@ -225,8 +225,13 @@ bool use_tuned_gemm(const ed_model* m, const GemmProblem& p) {
 int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
-  if (use_tuned_gemm(m, p)) LAUNCH_TRY(launch_gemm_bf16(p, s));
-  else LAUNCH_TRY(launch_gemm_generic(p, s));
+  if (use_tuned_gemm(m, p)) {
+    LAUNCH_TRY(launch_gemm_bf16(p, s));
+    if (kind == ED_K_CONV && !conv_window_supported(p)) kind = ED_K_CONV_OTHER;
+  } else {
+    LAUNCH_TRY(launch_gemm_generic(p, s));
+    if (kind == ED_K_CONV) kind = ED_K_CONV_OTHER;
+  }
   double taps = 0;
   for (int t = 0; t < p.ntaps; ++t) {
     const long off = std::labs((long)(t - p.ntaps / 2) * p.dilation);

@@ -56,7 +56,10 @@ typedef struct ed_config {
 typedef struct ed_model ed_model;
 
 /* Per-kernel-class probe record (see ed_probe_*): device time by HIP events around launches. */
-enum { ED_K_EMBED = 0, ED_K_LNACT = 1, ED_K_GEMM1X1 = 2, ED_K_CONV = 3, ED_K_FINAL = 4, ED_K_COUNT = 5 };
+/* ED_K_CONV: launches of the windowed convolution kernel (conv_window.hip, dilation <= 16), the dominant kernel;
+ * ED_K_CONV_OTHER: convolutions that went to the per-tap or the small-tile kernel. */
+enum { ED_K_EMBED = 0, ED_K_LNACT = 1, ED_K_GEMM1X1 = 2, ED_K_CONV = 3, ED_K_FINAL = 4, ED_K_CONV_OTHER = 5,
+       ED_K_COUNT = 6 };
 typedef struct ed_probe_stat {
   double ms;          /* summed device time of the probed launches */
   double flops;       /* summed algorithmic FLOPs (in-range taps only) of those launches */
