@@ -3,6 +3,7 @@
 #include "../../include/evodiff_hip.h"
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -104,8 +105,10 @@ struct ed_model {
   // workspace
   int ws_B = 0, ws_L = 0, ws_prec = -1;
   DevBuf X, X2, Abuf, Ybuf, Cpad, Cprune, state, tok, order, uni, qbuf, tvec;
+  DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
+  int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   bool prune = true;           // ED_OPT_PRUNE
-  int min_tuned_tiles = 96;    // ED_OPT_MIN_TUNED_TILES
+  int min_tuned_tiles = 40;    // ED_OPT_MIN_TUNED_TILES
   std::vector<LayerPlan> plan; // per layer, for the current (B, L)
   int plan_s_final = 1;        // stride of the position set the last block produces
   long conv_pitch = 0, conv_row0 = 0;  // layout of Cpad: [B][conv_pitch][d_hidden], position 0 at row conv_row0
@@ -229,7 +232,21 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
     LAUNCH_TRY(launch_gemm_bf16(p, s));
     if (kind == ED_K_CONV && !conv_window_supported(p)) kind = ED_K_CONV_OTHER;
   } else {
-    LAUNCH_TRY(launch_gemm_generic(p, s));
+    // Small problems in the fast path: a few workgroups streaming cold weights are latency-bound, so the K loop
+    // is cut across workgroups (deterministic: partial sums to a workspace, added up in a fixed order).
+    GemmProblem q = p;
+    if (p.a_bf16 && m->split_target > 0 && m->partials.p) {
+      const long tiles = (long)p.B * ((p.L + 127) / 128) * ((p.N + 127) / 128);
+      const int iters = p.ntaps * ((p.K + 63) / 64);
+      long ks = std::min<long>({m->split_target / tiles, (long)iters / 4, 16L});
+      while (ks > 1 && (size_t)ks * p.B * p.L * p.N * 4 > m->partials.bytes) --ks;
+      if (ks > 1) {
+        q.ksplit = (int)ks;
+        q.partial = m->partials.as<float>();
+      }
+    }
+    LAUNCH_TRY(launch_gemm_generic(q, s));
+    if (q.ksplit > 1) LAUNCH_TRY(launch_reduce_partials(q, s));
     if (kind == ED_K_CONV) kind = ED_K_CONV_OTHER;
   }
   double taps = 0;
@@ -312,6 +329,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   HIP_TRY(need(m->Cprune, pbytes));
   if (prelayout && m->Cprune.p) HIP_TRY(hipMemsetAsync(m->Cprune.p, 0, m->Cprune.bytes, s));
   if (m->plan_s_final > 1) HIP_TRY(need(m->X2, ((size_t)B * L / 2 + 256) * c.d_model * 4));
+  HIP_TRY(need(m->partials, (size_t)32 << 20));
   if (pitch != m->conv_pitch) grew = true;  // the graphs bake the pitch in
   m->ws_prec = prec;
   m->conv_pitch = pitch;
@@ -816,6 +834,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_PRUNE:
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_PRUNE takes 0 or 1");
       m->prune = value != 0;
+      break;
+    case ED_OPT_SPLIT_TARGET:
+      if (value < 0 || value > 4096) return fail(ED_EINVAL, "ED_OPT_SPLIT_TARGET must be in [0, 4096]");
+      m->split_target = value;
       break;
     case ED_OPT_MIN_TUNED_TILES:
       if (value < 0) return fail(ED_EINVAL, "ED_OPT_MIN_TUNED_TILES must be >= 0");

@@ -349,19 +349,27 @@ __device__ __forceinline__ float row_logits(const float* X, long row, int D, int
     }
   }
   float mine = 0.f;
-  for (int k = 0; k < n_out; ++k) {
-    float s = 0.f;
+  // four outputs at a time: their weight loads are independent, so one memory round trip serves four dot products
+  for (int k0 = 0; k0 < n_out; k0 += 4) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int idx = (c * 64 + lane) * 4;
-      if (idx < D) {
-        const float4 w = *(const float4*)(dec_w + (long)k * D + idx);
-        s = fmaf(v[c][0], w.x, s); s = fmaf(v[c][1], w.y, s);
-        s = fmaf(v[c][2], w.z, s); s = fmaf(v[c][3], w.w, s);
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u < n_out ? k0 + u : n_out - 1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int idx = (c * 64 + lane) * 4;
+        if (idx < D) {
+          const float4 w = *(const float4*)(dec_w + (long)k * D + idx);
+          s[u] = fmaf(v[c][0], w.x, s[u]); s[u] = fmaf(v[c][1], w.y, s[u]);
+          s[u] = fmaf(v[c][2], w.z, s[u]); s[u] = fmaf(v[c][3], w.w, s[u]);
+        }
       }
     }
-    s = wave_sum(s) + dec_b[k];
-    if (lane == k) mine = s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = wave_sum_dpp(s[u]);
+      if (k0 + u < n_out && lane == k0 + u) mine = t + dec_b[k0 + u];
+    }
   }
   return mine;
 }

@@ -49,7 +49,12 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   int tap_lo = 0, tap_hi = g.ntaps - 1;
   while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
   while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
-  const int it_begin = tap_lo * ksteps, it_end = (tap_hi + 1) * ksteps;
+  int it_begin = tap_lo * ksteps, it_end = (tap_hi + 1) * ksteps;
+  if (g.ksplit > 1) {  // this workgroup's share of the K loop
+    const int chunk = (it_end - it_begin + g.ksplit - 1) / g.ksplit;
+    it_begin += (int)blockIdx.z * chunk;
+    it_end = it_begin + chunk < it_end ? it_begin + chunk : it_end;
+  }
 
   const char* Abase = (const char*)g.A;
   const char* Wbase = (const char*)g.W;
@@ -144,6 +149,22 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     if (it + 1 < it_end) step(it + 1, ra[1], rb[1]);
   }
 
+  if (g.ksplit > 1) {  // raw partial sums; bias, residual and rounding happen in the reduction
+    float* part = g.partial + (long)blockIdx.z * g.B * g.L * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + fr;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (l < g.L) part[((long)b * g.L + l) * g.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   const int rsel = RESID ? g.resid_sel.get() : 0;
   // epilogue: C[row][col] with col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -166,13 +187,52 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     }
 }
 
+// out[r][n] = bias[n] (+ resid[r * resid_mul + sel][n]) + partial[0][r][n] + partial[1][r][n] + ...  (fixed order)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(GemmProblem g) {
+  const long rows = (long)g.B * g.L, quads = rows * g.N / 4;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const long e = q * 4, r = e / g.N;
+  const int n = (int)(e - r * g.N);
+  float4 s = *(const float4*)(g.bias + n);
+  if (g.resid) {
+    const float4 x = *(const float4*)(g.resid + (r * g.resid_mul + g.resid_sel.get()) * g.N + n);
+    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+  }
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < g.ksplit; ++z) {
+    const float4 p = *(const float4*)(g.partial + z * rows * g.N + e);
+    t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+  }
+  s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  if constexpr (OUT_BF16) {
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16_bits(s.x) | ((unsigned)f32_to_bf16_bits(s.y) << 16);
+    pk.y = (unsigned)f32_to_bf16_bits(s.z) | ((unsigned)f32_to_bf16_bits(s.w) << 16);
+    *(uint2*)((bf16_t*)g.out + e) = pk;
+  } else {
+    *(float4*)((float*)g.out + e) = s;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_reduce_partials(const GemmProblem& p, hipStream_t stream) {
+  if (p.ksplit < 2 || !p.partial || p.N % 4 != 0) return hipErrorInvalidValue;
+  const long quads = (long)p.B * p.L * p.N / 4;
+  const dim3 grid((unsigned)((quads + 255) / 256)), block(256);
+  if (p.out_bf16) hipLaunchKernelGGL(reduce_partials_kernel<true>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(reduce_partials_kernel<false>, grid, block, 0, stream, p);
+  return hipGetLastError();
+}
 
 hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream) {
   const int kstep = p.a_bf16 ? 32 : 16;  // 64 bytes: the unit the kernel masks the K tail in
   if (p.K % kstep != 0 || p.B <= 0 || p.L <= 0 || p.N <= 0 || (p.ntaps & 1) == 0) return hipErrorInvalidValue;
   if (p.resid && p.out_bf16) return hipErrorInvalidValue;
-  dim3 grid((p.N + BN - 1) / BN, (unsigned)(p.B * ((p.L + BM - 1) / BM)));
+  if (p.ksplit < 1 || (p.ksplit > 1 && !p.partial)) return hipErrorInvalidValue;
+  dim3 grid((p.N + BN - 1) / BN, (unsigned)(p.B * ((p.L + BM - 1) / BM)), (unsigned)p.ksplit);
   dim3 block(256);
 #define ED_LAUNCH(BF, OB, RS) hipLaunchKernelGGL((gemm_generic_kernel<BF, OB, RS>), grid, block, 0, stream, p)
   if (p.a_bf16) {

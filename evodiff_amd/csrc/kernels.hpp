@@ -48,12 +48,16 @@ struct GemmProblem {
   bool out_bf16;        // element type of out (resid != nullptr requires fp32 out)
   int resid_mul = 1;    // the residual of output row R is row R * resid_mul + resid_sel.get() of `resid`
   PosBit resid_sel;     //   (resid_mul > 1: every resid_mul-th row of a longer buffer; then resid must not alias out)
+  int ksplit = 1;       // generic kernel only: the K loop is cut into ksplit ranges (grid.z); range z writes its raw fp32
+  float* partial = nullptr;  //   sums to partial[z][B*L][N] and launch_reduce_partials adds them up in a fixed order
   long long* stamps = nullptr;  // diagnostics (ablate == 7): per tile {shader cycles, 100-MHz ticks} of the K loop
   int ablate = 0;       // diagnostics of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong), 3 = no window form
 };
 
 // Reference-quality tile kernel: any shape with K % 32 == 0 (bf16) / K % 16 == 0 (fp32).
 hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream);
+// out = bias (+ resid through the problem's row map) + sum_z partial[z], for a problem run with ksplit > 1.
+hipError_t launch_reduce_partials(const GemmProblem& p, hipStream_t stream);
 // Tuned bf16 kernel (see gemm_bf16.hip for its shape requirements); false = shape not supported.
 bool gemm_bf16_supported(const GemmProblem& p);
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream);

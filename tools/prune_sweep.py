@@ -15,9 +15,11 @@ dev = torch.device("cuda", 0)
 B, L, n = 64, 256, 32
 order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
 uni = torch.rand((n, B), device=dev)
-for prune, tiles in ((0, 0), (0, 96), (1, 0), (1, 48), (1, 96), (1, 130), (1, 200)):
+for prune, tiles, split in ((0, 96, 512), (1, 96, 0), (1, 96, 256), (1, 96, 512), (1, 96, 1024), (1, 96, 2048), (1, 130, 1024),
+                            (1, 40, 1024)):
     m.set_option("prune", prune)
     m.set_option("min_tuned_tiles", tiles)
+    m.set_option("split_target", split)
     best = 1e9
     for rep in range(3):
         sample = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
@@ -26,4 +28,5 @@ for prune, tiles in ((0, 0), (0, 96), (1, 0), (1, 48), (1, 96), (1, 130), (1, 20
         m.oadm_sample(sample, order, uni, 21)
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / n)
-    print(f"prune={prune} min_tuned_tiles={tiles:4d}: {best * 1e3:.3f} ms/step -> {B / (best * L):.3f} seq/s", flush=True)
+    print(f"prune={prune} min_tuned_tiles={tiles:4d} split_target={split:5d}: {best * 1e3:.3f} ms/step -> "
+          f"{B / (best * L):.3f} seq/s", flush=True)
