@@ -309,6 +309,99 @@ def test_full_size_batch_invariance_640m(dev):
     assert (pb2[0] - pb[0]).abs().max() < 2e-2
 
 
+def test_d3pm_640m_steps_vs_oracle_and_full_batch(dev):
+    """BASELINE config 3 (D3PM_BLOSUM_640M, B=64, L=256): single steps at t = 499, 250 and 1 against the oracle at
+    B=2 (fp32 posterior 2e-5; bf16 draws outside the margin), then the full batch: rows of a 64-batch bf16 run
+    equal the same rows sampled in a batch of 2 (sequences are independent)."""
+    from evodiff_amd.utils import DEFAULT_BLOSUM, Tokenizer
+    cfg = R.MODEL_CONFIGS["640M"]
+    oracle = R.build_model(cfg, 500, 3)
+    m = product_model(oracle, cfg, timesteps=500, precision="fp32")
+    tok = Tokenizer(path_to_blosum=DEFAULT_BLOSUM, sequences=True)
+    Qbar, Q = tok.q_blosum_schedule(timesteps=500)
+    B, L, K = 64, 256, tok.K
+    rng = np.random.default_rng(2)
+    start = torch.from_numpy(rng.integers(0, K, (B, L)))
+    uni = torch.from_numpy(np.random.default_rng(3).random((500, B, L), dtype=np.float32))
+    small, uni_small = start[62:64].contiguous(), uni[:, 62:64].contiguous()
+    for t in (499, 250, 1):
+        ref_tok, _, ref_post, margin = R.d3pm_step(oracle, small, t, Q, Qbar, uni_small[499 - t], K,
+                                                   u_final=uni_small[499])
+        for precision, ptol, mtol in (("fp32", 2e-5, DRAW_MARGIN_FP32), ("bf16", 5e-2, DRAW_MARGIN_BF16)):
+            m.precision = precision
+            sample = small.clone().to(dev)
+            post = m.d3pm_sample(sample, Q, Qbar, uni_small, K, t_start=t, n_steps=1, return_post=True)
+            assert np.abs(post[0].cpu().numpy() - ref_post.numpy()).max() < ptol
+            n_safe = _check_draws(sample.cpu().numpy(), ref_tok.numpy(), margin.numpy(), mtol)
+            assert n_safe > 0.5 * small.numel()
+    m.precision = "bf16"
+    m.set_option("min_tuned_tiles", 0)       # one GEMM kernel at both batch sizes: the same arithmetic per row
+    big = start.clone().to(dev)
+    m.d3pm_sample(big, Q, Qbar, uni, K, t_start=3, n_steps=3)
+    two = small.clone().to(dev)
+    m.d3pm_sample(two, Q, Qbar, uni_small, K, t_start=3, n_steps=3)
+    assert torch.equal(big[62:64], two)
+    assert int(big.max()) < K - 6            # the chain ended at t == 1: canonical amino acids only
+
+
+def test_640m_length_512_two_tiles_per_sequence(dev):
+    """Geometry of BASELINE config 4 (L=512: two 256-row tiles per sequence, dilation halos crossing the tile
+    boundary, pruning down to one row of 512): OA-DM steps against the oracle at B=2."""
+    cfg = R.MODEL_CONFIGS["640M"]
+    oracle = R.build_model(cfg, None, 4)
+    m = product_model(oracle, cfg, precision="fp32")
+    B, L = 2, 512
+    rng = np.random.default_rng(5)
+    state = torch.full((B, L), R.MASK_ID, dtype=torch.long)
+    state[:, rng.permutation(L)[: L // 3]] = torch.from_numpy(rng.integers(0, 20, (B, L // 3)))
+    zeros = torch.zeros(B, dtype=torch.long, device=dev)
+    for pos, u in ((0, 0.3), (255, 0.9), (256, 0.5), (511, 0.1)):
+        uu = torch.full((B,), u)
+        nxt, logits, p, margin = R.oadm_step(oracle, state, pos, uu)
+        for precision, tol, mtol in (("fp32", FP32_TOL, DRAW_MARGIN_FP32), ("bf16", BF16_TOL, DRAW_MARGIN_BF16)):
+            m.precision = precision
+            if pos == 256:
+                assert rel_err(m(state.to(dev), zeros).cpu().numpy(), logits.numpy()) < tol
+            sample = state.clone().to(dev)
+            probs = m.oadm_sample(sample, torch.tensor([pos]), uu.view(1, B).to(dev), R.OADM_DRAW, return_probs=True)
+            assert np.abs(probs[0].cpu().numpy() - p.numpy()).max() < (1e-5 if precision == "fp32" else 5e-2)
+            safe = margin.numpy() > mtol
+            assert np.array_equal(sample[:, pos].cpu().numpy()[safe], nxt[:, pos].numpy()[safe])
+        state = nxt
+
+
+def test_38m_config5_full_size_batch_invariance(dev):
+    """BASELINE config 5 (OA_DM_38M, B=1024, L=1024, bf16; N-tile 256 kernels, four tiles per sequence): rows of the
+    full batch equal the same rows sampled in a batch of 4, and that small batch follows the oracle."""
+    from evodiff_amd.pretrained import OA_DM_38M
+    torch.manual_seed(0)
+    m, _, tok, _ = OA_DM_38M(random_init=True)
+    m.precision = "bf16"
+    m.set_option("min_tuned_tiles", 0)
+    m.set_option("prune", 0)
+    B, L, n = 1024, 1024, 2
+    order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
+    uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32)).to(dev)
+    big = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
+    pb = m.oadm_sample(big, order, uni, R.OADM_DRAW, return_probs=True)
+    small = torch.full((4, L), tok.mask_id, dtype=torch.long, device=dev)
+    ps = m.oadm_sample(small, order, uni[:, 1020:1024].contiguous(), R.OADM_DRAW, return_probs=True)
+    assert torch.equal(big[1020:1024], small)
+    assert torch.equal(pb[:, 1020:1024], ps)
+    assert int((big != tok.mask_id).sum()) == B * n
+    # the small batch against the oracle (same seeded default init), first step, default execution options
+    m.set_option("min_tuned_tiles", 40)
+    m.set_option("prune", 1)
+    torch.manual_seed(0)
+    oracle = R.build_model(R.MODEL_CONFIGS["38M"], None, None)
+    oracle.load_state_dict(m.state_dict())
+    state = torch.full((4, L), R.MASK_ID, dtype=torch.long)
+    _, _, p_ref, _ = R.oadm_step(oracle, state, int(order[0]), uni[0, 1020:1024].cpu())
+    again = state.clone().to(dev)
+    p_got = m.oadm_sample(again, order[:1], uni[:1, 1020:1024].contiguous(), R.OADM_DRAW, return_probs=True)
+    assert np.abs(p_got[0].cpu().numpy() - p_ref.numpy()).max() < 5e-2
+
+
 def test_errors_are_raised_not_faults(dev):
     from evodiff_amd import _lib
     oracle = R.build_model(TINY, None, 1)
