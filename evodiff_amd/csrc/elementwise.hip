@@ -235,99 +235,100 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-template <int NCH, bool IN_BF16, int RPW>
+// Row layout of a wave: NC8 chunks of 512 channels at 8 per lane (16-byte bf16 / 2 x 16-byte fp32 accesses), then
+// NC4 chunks of 256 channels at 4 per lane for the rest (masked past C).  1280 = 2 x 512 + 256.
+template <int NC8, int NC4, bool IN_BF16, int ACT>
 __global__ __launch_bounds__(256) void ln_act_fast_kernel(const void* __restrict__ in, bf16_t* __restrict__ out,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int rows, int C,
-                                                          LnRowMap map, int act) {
-  typedef typename std::conditional<IN_BF16, uint2, float4>::type raw_t;
+                                                          LnRowMap map) {
+  constexpr int NV = NC8 * 8 + NC4 * 4;  // values per lane
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-  const int row0 = wave * RPW;
-  if (row0 >= rows) return;
-  const int nrows = rows - row0 < RPW ? rows - row0 : RPW;
+  const int row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (row >= rows) return;
   const unsigned rps = (unsigned)map.rows_per_seq;
-  const int sel = map.in_sel.get();
+  const unsigned seq = (unsigned)row / rps, m = (unsigned)row - seq * rps;
+  const long irow = map.in_row0 + (long)seq * map.in_pitch + (long)m * map.in_mul + map.in_sel.get();
+  const long orow = map.out_row0 + (long)seq * map.out_pitch + m;
+  // channel index of value slot k (a multiple of 4 slots shares one 16-byte piece of gamma / beta)
+  auto chan = [&](int k) { return k < NC8 * 8 ? ((k >> 3) * 64 + lane) * 8 + (k & 7) : NC8 * 512 + (((k - NC8 * 8) >> 2) * 64 + lane) * 4 + (k & 3); };
 
-  float4 gm[NCH], bt[NCH];
+  float v[NV];
+  if constexpr (IN_BF16) {
+    const bf16_t* src = (const bf16_t*)in + irow * C;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int idx = (c * 64 + lane) * 4;
-    if (idx < C) {
-      gm[c] = *(const float4*)(gamma + idx);
-      bt[c] = *(const float4*)(beta + idx);
+    for (int c = 0; c < NC8; ++c) {
+      const uint4 raw = *(const uint4*)(src + chan(c * 8));
+      const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[c * 8 + 2 * j] = __uint_as_float(w[j] << 16);
+        v[c * 8 + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC4; ++c) {
+      const int k = NC8 * 8 + c * 4;
+      uint2 raw = make_uint2(0, 0);
+      if (chan(k) < C) raw = *(const uint2*)(src + chan(k));
+      v[k] = __uint_as_float(raw.x << 16);
+      v[k + 1] = __uint_as_float(raw.x & 0xffff0000u);
+      v[k + 2] = __uint_as_float(raw.y << 16);
+      v[k + 3] = __uint_as_float(raw.y & 0xffff0000u);
+    }
+  } else {
+    const float* src = (const float*)in + irow * C;
+#pragma unroll
+    for (int k = 0; k < NV; k += 4) {
+      float4 raw = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < NC8 * 8 || chan(k) < C) raw = *(const float4*)(src + chan(k));
+      v[k] = raw.x; v[k + 1] = raw.y; v[k + 2] = raw.z; v[k + 3] = raw.w;
     }
   }
-  auto in_row = [&](int row) -> long {
-    const unsigned seq = (unsigned)row / rps, m = (unsigned)row - seq * rps;
-    return map.in_row0 + (long)seq * map.in_pitch + (long)m * map.in_mul + sel;
-  };
-  auto out_row = [&](int row) -> long {
-    const unsigned seq = (unsigned)row / rps, m = (unsigned)row - seq * rps;
-    return map.out_row0 + (long)seq * map.out_pitch + m;
-  };
-  auto load_raw = [&](long irow, raw_t (&raw)[NCH]) {
+  float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int idx = (c * 64 + lane) * 4;
-      if (idx < C) {
-        if constexpr (IN_BF16) raw[c] = *(const uint2*)((const bf16_t*)in + irow * C + idx);
-        else raw[c] = *(const float4*)((const float*)in + irow * C + idx);
-      }
-    }
-  };
-
-  raw_t cur[NCH], nxt[NCH];
-  load_raw(in_row(row0), cur);
+  for (int k = 0; k < NV; ++k) {  // masked slots hold zeros
+    s += v[k];
+    q = fmaf(v[k], v[k], q);
+  }
+  s = wave_sum_dpp(s);
+  q = wave_sum_dpp(q);
   const float inv = 1.0f / (float)C;
-  for (int i = 0; i < nrows; ++i) {
-    if (i + 1 < nrows) load_raw(in_row(row0 + i + 1), nxt);
-    float v[NCH][4];
-    float s = 0.f, q = 0.f;
+  const float mean = s * inv;
+  const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + LN_EPS);
+  const float shift = -mean * rstd;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+  bf16_t* dst = out + orow * C;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int idx = (c * 64 + lane) * 4;
-      if (idx < C) {
-        if constexpr (IN_BF16) {
-          v[c][0] = __uint_as_float(cur[c].x << 16);
-          v[c][1] = __uint_as_float(cur[c].x & 0xffff0000u);
-          v[c][2] = __uint_as_float(cur[c].y << 16);
-          v[c][3] = __uint_as_float(cur[c].y & 0xffff0000u);
-        } else {
-          v[c][0] = cur[c].x; v[c][1] = cur[c].y; v[c][2] = cur[c].z; v[c][3] = cur[c].w;
-        }
+  for (int k = 0; k < NV; k += 4) {
+    const bool on = k < NC8 * 8 || chan(k) < C;
+    if (on) {
+      const float4 gm = *(const float4*)(gamma + chan(k));
+      const float4 bt = *(const float4*)(beta + chan(k));
+      const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s += v[c][j];
-          q = fmaf(v[c][j], v[c][j], q);
-        }
+      for (int j = 0; j < 4; ++j) {
+        float y = fmaf(fmaf(v[k + j], rstd, shift), g4[j], b4[j]);
+        if constexpr (ACT == 1) y = gelu_sigmoid_fit(y);
+        else if constexpr (ACT == 2) y = fmaxf(y, 0.f);
+        v[k + j] = y;
       }
     }
-    s = wave_sum_dpp(s);
-    q = wave_sum_dpp(q);
-    const float mean = s * inv;
-    const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + LN_EPS);
-    const float shift = -mean * rstd;
-    bf16_t* orow = out + out_row(row0 + i) * C;
+  }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int idx = (c * 64 + lane) * 4;
-      if (idx < C) {
-        const float g4[4] = {gm[c].x, gm[c].y, gm[c].z, gm[c].w}, b4[4] = {bt[c].x, bt[c].y, bt[c].z, bt[c].w};
-        float y[4];
+  for (int c = 0; c < NC8; ++c) {
+    const bf16x8v pk = {(__bf16)v[c * 8], (__bf16)v[c * 8 + 1], (__bf16)v[c * 8 + 2], (__bf16)v[c * 8 + 3],
+                        (__bf16)v[c * 8 + 4], (__bf16)v[c * 8 + 5], (__bf16)v[c * 8 + 6], (__bf16)v[c * 8 + 7]};
+    *(bf16x8v*)(dst + chan(c * 8)) = pk;  // v_cvt_pk_bf16_f32 (RNE)
+  }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          y[j] = fmaf(fmaf(v[c][j], rstd, shift), g4[j], b4[j]);
-          if (act == 1) y[j] = gelu_sigmoid_fit(y[j]);
-          else if (act == 2) y[j] = fmaxf(y[j], 0.f);
-        }
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        const bf16x4 pk = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};  // v_cvt_pk_bf16_f32 (RNE)
-        *(bf16x4*)(orow + idx) = pk;
-      }
+  for (int c = 0; c < NC4; ++c) {
+    const int k = NC8 * 8 + c * 4;
+    if (chan(k) < C) {
+      const bf16x4 pk = {(__bf16)v[k], (__bf16)v[k + 1], (__bf16)v[k + 2], (__bf16)v[k + 3]};
+      *(bf16x4*)(dst + chan(k)) = pk;
     }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
   }
 }
 
@@ -517,16 +518,26 @@ hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16,
     // one row per wave measured fastest (2/4/8 rows per wave with a register prefetch of the next row: +1..+7 us
     // at config-2 size; 1-16 waves per block: no difference)
     const dim3 fgrid((rows + 3) / 4), fblock(256);
-#define ED_FAST(N)                                                                                             \
-    if (in_bf16)                                                                                               \
-      hipLaunchKernelGGL((ln_act_fast_kernel<N, true, 1>), fgrid, fblock, 0, stream, in, (bf16_t*)out, gamma,  \
-                         beta, rows, C, map, act);                                                             \
-    else                                                                                                       \
-      hipLaunchKernelGGL((ln_act_fast_kernel<N, false, 1>), fgrid, fblock, 0, stream, in, (bf16_t*)out, gamma, \
-                         beta, rows, C, map, act)
-    ED_NCH_DISPATCH(C, ED_FAST);
+    const int nc8 = C / 512, nc4 = (C % 512 + 255) / 256;
+#define ED_FAST_ACT(A8, A4, AC)                                                                                  \
+    if (act == AC) {                                                                                             \
+      if (in_bf16)                                                                                               \
+        hipLaunchKernelGGL((ln_act_fast_kernel<A8, A4, true, AC>), fgrid, fblock, 0, stream, in, (bf16_t*)out,   \
+                           gamma, beta, rows, C, map);                                                           \
+      else                                                                                                       \
+        hipLaunchKernelGGL((ln_act_fast_kernel<A8, A4, false, AC>), fgrid, fblock, 0, stream, in, (bf16_t*)out,  \
+                           gamma, beta, rows, C, map);                                                           \
+    }
+#define ED_FAST(A8, A4)                                                                                          \
+    if (nc8 == A8 && nc4 == A4) {                                                                                \
+      ED_FAST_ACT(A8, A4, 0) ED_FAST_ACT(A8, A4, 1) ED_FAST_ACT(A8, A4, 2)                                       \
+      return hipGetLastError();                                                                                  \
+    }
+    ED_FAST(0, 1) ED_FAST(0, 2) ED_FAST(1, 0) ED_FAST(1, 1) ED_FAST(1, 2) ED_FAST(2, 0) ED_FAST(2, 1) ED_FAST(2, 2)
+    ED_FAST(3, 0) ED_FAST(3, 1) ED_FAST(3, 2) ED_FAST(4, 0)
 #undef ED_FAST
-    return hipGetLastError();
+#undef ED_FAST_ACT
+    return hipErrorInvalidValue;
   }
   const dim3 grid((rows + 3) / 4), block(256);
 #define ED_CALL(N)                                                                                            \
