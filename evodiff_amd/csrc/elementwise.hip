@@ -221,6 +221,26 @@ __device__ __forceinline__ float gelu_sigmoid_fit(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
 }
 
+// two elements at a time: hipcc selects the packed fp32 instructions (v_pk_mul/fma/add_f32) for <2 x float>
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_sigmoid_fit2(f32x2 x) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float A = -1.59501577f * LOG2E, B = -7.40112924e-02f * LOG2E, C = 7.03033587e-04f * LOG2E;
+  f32x2 xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -9.0f, 9.0f);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -9.0f, 9.0f);
+  const f32x2 x2 = xc * xc;
+  const f32x2 w = xc * __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, (f32x2)(C), (f32x2)(B)), (f32x2)(A));
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(w.x);
+  e.y = __builtin_amdgcn_exp2f(w.y);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return x * r;
+}
+
 // sum over the 64 lanes, result in every lane (all lanes active)
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
@@ -285,14 +305,15 @@ __global__ __launch_bounds__(256) void ln_act_fast_kernel(const void* __restrict
       v[k] = raw.x; v[k + 1] = raw.y; v[k + 2] = raw.z; v[k + 3] = raw.w;
     }
   }
-  float s = 0.f, q = 0.f;
+  f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {  // masked slots hold zeros
-    s += v[k];
-    q = fmaf(v[k], v[k], q);
+  for (int k = 0; k < NV; k += 2) {  // masked slots hold zeros
+    const f32x2 v2 = {v[k], v[k + 1]};
+    s2 += v2;
+    q2 = __builtin_elementwise_fma(v2, v2, q2);
   }
-  s = wave_sum_dpp(s);
-  q = wave_sum_dpp(q);
+  const float s = wave_sum_dpp(s2.x + s2.y);
+  const float q = wave_sum_dpp(q2.x + q2.y);
   const float inv = 1.0f / (float)C;
   const float mean = s * inv;
   const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + LN_EPS);
@@ -306,13 +327,15 @@ __global__ __launch_bounds__(256) void ln_act_fast_kernel(const void* __restrict
     if (on) {
       const float4 gm = *(const float4*)(gamma + chan(k));
       const float4 bt = *(const float4*)(beta + chan(k));
-      const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+      const f32x2 g2[2] = {{gm.x, gm.y}, {gm.z, gm.w}}, b2[2] = {{bt.x, bt.y}, {bt.z, bt.w}};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float y = fmaf(fmaf(v[k + j], rstd, shift), g4[j], b4[j]);
-        if constexpr (ACT == 1) y = gelu_sigmoid_fit(y);
-        else if constexpr (ACT == 2) y = fmaxf(y, 0.f);
-        v[k + j] = y;
+      for (int j = 0; j < 2; ++j) {
+        const f32x2 v2 = {v[k + 2 * j], v[k + 2 * j + 1]};
+        f32x2 y = __builtin_elementwise_fma(__builtin_elementwise_fma(v2, (f32x2)(rstd), (f32x2)(shift)), g2[j], b2[j]);
+        if constexpr (ACT == 1) y = gelu_sigmoid_fit2(y);
+        else if constexpr (ACT == 2) y = __builtin_elementwise_max(y, (f32x2)(0.f));
+        v[k + 2 * j] = y.x;
+        v[k + 2 * j + 1] = y.y;
       }
     }
   }
