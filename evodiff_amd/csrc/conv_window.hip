@@ -38,9 +38,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Geometry of the window (host-computed, the same for every tile of a launch).
+struct WindowPlan {
+  int win_groups;  // 8-row copy groups of the window
+  int wofs;        // window rows in front of the tile's first position (2d; whole-sequence form: 32 or 0)
+  int tap_lo, tap_hi;  // taps in the K loop (whole-sequence form drops taps no position of the tile can reach)
+  int clip;        // whole-sequence form: a wave skips the taps that move all of its 64 rows outside [0, 256)
+  int na;          // window groups each wave copies per step (1 or 2)
+};
+
 // STAMP: diagnostic build that also records the K loop's duration (GemmProblem::stamps).
 template <int NT, bool OUT_BF16, bool STAMP = false>
-__global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total, int win_groups) {
+__global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total, WindowPlan wp) {
   constexpr int BN = NT * 64;
   constexpr int W_BYTES = BN * ROW_B;
   constexpr int NGB = BN / 64;     // 8-row copy groups of the weight tile per wave and step
@@ -67,6 +76,7 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   const int l0 = (tile_m - b * tiles_per_seq) * BM;
   const int n0 = tile_n * BN;
   const int ksteps = g.K / BK, d = g.dilation;
+  const int win_groups = wp.win_groups, ntaps = wp.tap_hi - wp.tap_lo + 1;
 
   // ---- copy addressing: lane -> (row in 8-row group, physical 16-B chunk); logical chunk = physical ^ swizzle,
   // swizzle of window / tile row p = (p >> 1) & 7 = 4 * (group parity) + (lane >> 4)
@@ -75,12 +85,12 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   const unsigned lane_off0 = lane_row + (((lane & 7) ^ (lane >> 4)) << 4);
   const unsigned lane_off1 = lane_row + (((lane & 7) ^ (4 + (lane >> 4))) << 4);
   const unsigned grp_bytes = (unsigned)(8 * row_bytes);
-  // window row 0 = position l0 - 2d of sequence b
-  const char* a_next = (const char*)g.A + ((long)b * g.a_seq_pitch + g.a_row0 + l0 - 2L * d) * row_bytes;
-  const char* w_dma = (const char*)g.W + (long)n0 * row_bytes;  // tap 0, slice 0, first channel of the tile
+  // window row 0 = position l0 - wofs of sequence b
+  const char* a_next = (const char*)g.A + ((long)b * g.a_seq_pitch + g.a_row0 + l0 - wp.wofs) * row_bytes;
+  const char* w_dma = (const char*)g.W + ((long)wp.tap_lo * g.N + n0) * row_bytes;  // first tap, slice 0, first channel
   const unsigned w_lane_extra = (unsigned)((lane >> 5) * 4 * row_bytes);  // permuted rows: group row k reads channel + 4*(k >> 2)
   const long w_tap_step = (long)g.N * row_bytes;
-  const long w_wrap_step = ROW_B - (long)(NTAPS - 1) * g.N * row_bytes;
+  const long w_wrap_step = ROW_B - (long)(ntaps - 1) * g.N * row_bytes;
 
   auto copy_window_group = [&](int ga_raw, char* win) {  // groups past the window re-copy its last one
     const int ga = ga_raw < win_groups ? ga_raw : win_groups - 1;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   // ---- fragment addressing: 16 rows x 32 channels per fragment, lane = (row fr, 8-channel chunk fq)
   const int b_rd = (wc * (BN / 2) + fr) * ROW_B;
   const int b_x = (fq ^ ((fr >> 1) & 7)) << 4;
-  const int a_row = wr * 64 + fr;  // window row of this lane's first activation fragment at tap 0
+  const int a_row = wr * 64 + fr + wp.wofs - 2 * d;  // window row of this lane's first activation fragment at tap 0
   bf16x8 fact[2][4], fw[RING];
 
   // prologue: window of slice 0 and weights of step 0
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
     for (int k = 0; k < WIN_ROWS / 64; ++k) copy_window_group(k * 8 + wid, lds);
 #pragma unroll
     for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, lds_w);
-    w_dma += w_tap_step;
+    w_dma += ntaps > 1 ? w_tap_step : w_wrap_step;
     a_next += ksteps > 1 ? ROW_B : 0;
     __syncthreads();
   }
@@ -129,42 +139,53 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   // One step = tap TAP of one 64-channel slice: 2 k-slices of 32 x NJ column tiles x 4 position tiles = 8*NJ MFMAs.
   // The issue order is pinned; behind each MFMA comes at most one auxiliary instruction: the read of the weight
   // fragment three groups ahead, a read of the second k-slice's activation fragments, or one of the step's copies.
-  auto step = [&](auto tap_c, const char* win, char* win_next, const char* wst, char* wst_next) {
-    constexpr int TAP = decltype(tap_c)::value;
-    const int shift = TAP * d;  // window rows between tap 0 and this tap
-    const char* a_base = win + (a_row + shift) * ROW_B;
-    const int a_x = (fq ^ (((fr + shift) >> 1) & 7)) << 4;  // chunk of k-slice s: (s << 6) ^ a_x
-    const char* b_base = wst + b_rd;
-    auto read_act = [&](int s2, int ip) { fact[s2][ip] = *(const bf16x8*)(a_base + ip * 16 * ROW_B + ((s2 << 6) ^ a_x)); };
-    auto read_w = [&](int grp) {
-      const int s2 = grp / NJ, jn = grp - s2 * NJ;
-      fw[grp % RING] = *(const bf16x8*)(b_base + jn * 16 * ROW_B + ((s2 << 6) ^ b_x));
-    };
+  auto step = [&](int tap, int j, const char* win, char* win_next, const char* wst, char* wst_next) {
+    // whole-sequence form: rows [64 wr + (tap-2) d, +64) of this wave; all of them outside [0, 256) = all zeros
+    const int first = wr * 64 + (tap - 2) * d;
+    const bool active = !wp.clip || (first + 64 > 0 && first < BM);
+    if (active) {
+      const int shift = tap * d;  // window rows between tap 0 and this tap
+      const char* a_base = win + (a_row + shift) * ROW_B;
+      const int a_x = (fq ^ (((a_row + shift) >> 1) & 7)) << 4;  // chunk of k-slice s: (s << 6) ^ a_x
+      const char* b_base = wst + b_rd;
+      auto read_act = [&](int s2, int ip) { fact[s2][ip] = *(const bf16x8*)(a_base + ip * 16 * ROW_B + ((s2 << 6) ^ a_x)); };
+      auto read_w = [&](int grp) {
+        const int s2 = grp / NJ, jn = grp - s2 * NJ;
+        fw[grp % RING] = *(const bf16x8*)(b_base + jn * 16 * ROW_B + ((s2 << 6) ^ b_x));
+      };
 #pragma unroll
-    for (int ip = 0; ip < 4; ++ip) read_act(0, ip);
+      for (int ip = 0; ip < 4; ++ip) read_act(0, ip);
 #pragma unroll
-    for (int grp = 0; grp < RING - 1; ++grp) read_w(grp);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int grp = 0; grp < RING - 1; ++grp) read_w(grp);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int grp = 0; grp < NGRP; ++grp) {
-      const int s2 = grp / NJ, jn = grp - s2 * NJ;
+      for (int grp = 0; grp < NGRP; ++grp) {
+        const int s2 = grp / NJ, jn = grp - s2 * NJ;
 #pragma unroll
-      for (int ip = 0; ip < 4; ++ip) {
-        acc[jn][ip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[grp % RING], fact[s2][ip], acc[jn][ip], 0, 0, 0);
-        if (ip == 0) {
-          if (grp + RING - 1 < NGRP) read_w(grp + RING - 1);
-        } else if (ip == 1) {
-          if (grp >= 1 && grp <= 4) read_act(1, grp - 1);
-        } else if (ip == 2) {
-          if (grp >= 1 && grp <= NGB) copy_weight_group(grp - 1, wst_next);
-          else if (grp == NGB + 1) copy_window_group(TAP * 8 + wid, win_next);
+        for (int ip = 0; ip < 4; ++ip) {
+          acc[jn][ip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[grp % RING], fact[s2][ip], acc[jn][ip], 0, 0, 0);
+          if (ip == 0) {
+            if (grp + RING - 1 < NGRP) read_w(grp + RING - 1);
+          } else if (ip == 1) {
+            if (grp >= 1 && grp <= 4) read_act(1, grp - 1);
+          } else if (ip == 2) {
+            if (grp >= 1 && grp <= NGB) copy_weight_group(grp - 1, wst_next);
+            else if (grp == NGB + 1) copy_window_group((j * wp.na) * 8 + wid, win_next);
+            else if (grp == NGB + 2 && wp.na > 1) copy_window_group((j * wp.na + 1) * 8 + wid, win_next);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+      // nothing to multiply in this step: only this wave's share of the copies
+#pragma unroll
+      for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, wst_next);
+      copy_window_group((j * wp.na) * 8 + wid, win_next);
+      if (wp.na > 1) copy_window_group((j * wp.na + 1) * 8 + wid, win_next);
     }
   };
 
-  const int T = ksteps * NTAPS;
+  const int T = ksteps * ntaps;
   int t = 0;  // global step index
   unsigned long long c0 = 0, r0 = 0;
   if constexpr (STAMP) {
@@ -174,21 +195,13 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   for (int kc = 0; kc < ksteps; ++kc) {
     const char* win = lds + (kc & 1) * WIN_BYTES;
     char* win_next = lds + ((kc + 1) & 1) * WIN_BYTES;
-#define ED_TAP_STEP(TAPV)                                                                            \
-    {                                                                                                \
-      step(std::integral_constant<int, TAPV>{}, win, win_next, lds_w + (t & 1) * W_BYTES,            \
-           lds_w + ((t + 1) & 1) * W_BYTES);                                                         \
-      ++t;                                                                                           \
-      /* weights of step t+1: next tap, or tap 0 of the next slice; past the end the stream stalls */ \
-      w_dma += t + 1 < T ? (TAPV == NTAPS - 2 ? w_wrap_step : w_tap_step) : 0L;                      \
-      __syncthreads(); /* copies of this step landed (the fence drains them); stages free */         \
+    for (int j = 0; j < ntaps; ++j) {
+      step(wp.tap_lo + j, j, win, win_next, lds_w + (t & 1) * W_BYTES, lds_w + ((t + 1) & 1) * W_BYTES);
+      ++t;
+      // weights of step t+1: next tap, or the first tap of the next slice; past the end the stream stalls
+      w_dma += t + 1 < T ? (j == ntaps - 2 || ntaps == 1 ? w_wrap_step : w_tap_step) : 0L;
+      __syncthreads();  // copies of this step landed (the fence drains them); stages free
     }
-    ED_TAP_STEP(0)
-    ED_TAP_STEP(1)
-    ED_TAP_STEP(2)
-    ED_TAP_STEP(3)
-    ED_TAP_STEP(4)
-#undef ED_TAP_STEP
     a_next += kc + 2 < ksteps ? ROW_B : 0;
   }
   if constexpr (STAMP) {  // diagnostic build only: loop duration in shader cycles and in 100-MHz ticks
@@ -231,17 +244,40 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
 
 }  // namespace
 
-// Shape contract (on top of gemm_bf16_supported): five taps, window of 256 + 4*dilation rows within 320, no
-// residual.  Memory contract: A rows [a_row0 - 2*dilation, a_row0 + ceil(L/256)*256 + 2*dilation + 8) of every
-// sequence are readable, and rows outside [0, L) hold zeros.
-bool conv_window_supported(const GemmProblem& p) {
+// Shape contract (on top of gemm_bf16_supported): five taps, no residual, and either
+//  - the window of 256 + 4*dilation rows fits the 320-row LDS window (dilation <= 16), or
+//  - whole-sequence form: L <= 256 (one tile per sequence, so every row outside the tile is zero padding) and
+//    dilation 32 or a multiple of 64 - then each 64-row wave slice of a tap is either entirely padding (skipped)
+//    or inside the window [-wofs, 256 + wofs).
+// Memory contract: A rows [a_row0 - 2*dilation, a_row0 + ceil(L/256)*256 + 2*dilation + 8) of every sequence are
+// readable, and rows outside [0, L) hold zeros.
+static bool window_plan(const GemmProblem& p, WindowPlan* wp) {
   if (!gemm_bf16_supported(p) || p.ntaps != NTAPS || p.resid) return false;
-  return BM + 4 * p.dilation <= WIN_ROWS;
+  const int d = p.dilation;
+  if (BM + 4 * d <= WIN_ROWS) {
+    *wp = WindowPlan{(BM + 4 * d + 7) / 8, 2 * d, 0, NTAPS - 1, 0, 1};
+    return true;
+  }
+  if (p.L <= BM && (d == 32 || d % 64 == 0)) {
+    const int wofs = d == 32 ? 32 : 0;
+    int lo = 0, hi = NTAPS - 1;
+    while ((2 - lo) * d >= BM) ++lo;
+    while ((hi - 2) * d >= BM) --hi;
+    const int groups = (BM + 2 * wofs) / 8, nt = hi - lo + 1;
+    *wp = WindowPlan{groups, wofs, lo, hi, 1, (groups + 8 * nt - 1) / (8 * nt)};
+    return wp->na <= 2;
+  }
+  return false;
+}
+
+bool conv_window_supported(const GemmProblem& p) {
+  WindowPlan wp;
+  return window_plan(p, &wp);
 }
 
 hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream) {
-  if (!conv_window_supported(p)) return hipErrorInvalidValue;
-  const int win_groups = (BM + 4 * p.dilation + 7) / 8;
+  WindowPlan wp;
+  if (!window_plan(p, &wp)) return hipErrorInvalidValue;
   const dim3 block(512);
 #define ED_GO(NTV, OB)                                                                                   \
   {                                                                                                      \
@@ -249,10 +285,10 @@ hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream) {
     const int tiles_total = p.B * ((p.L + BM - 1) / BM) * tiles_n;                                       \
     if (p.ablate == 7 && p.stamps)                                                                       \
       hipLaunchKernelGGL((conv_window_kernel<NTV, OB, true>), dim3(tiles_total), block, 0, stream, p,    \
-                         tiles_n, tiles_total, win_groups);                                              \
+                         tiles_n, tiles_total, wp);                                              \
     else                                                                                                 \
       hipLaunchKernelGGL((conv_window_kernel<NTV, OB>), dim3(tiles_total), block, 0, stream, p, tiles_n, \
-                         tiles_total, win_groups);                                                       \
+                         tiles_total, wp);                                                       \
   }
   if (p.N % 320 == 0) {
     if (p.out_bf16) ED_GO(5, true) else ED_GO(5, false)
