@@ -75,9 +75,9 @@ struct LayerPlan {
 };
 
 struct GraphKey {
-  int mode, B, L, prec, n;
+  int mode, B, L, prec, n, variant;
   bool operator<(const GraphKey& o) const {
-    return std::tie(mode, B, L, prec, n) < std::tie(o.mode, o.B, o.L, o.prec, o.n);
+    return std::tie(mode, B, L, prec, n, variant) < std::tie(o.mode, o.B, o.L, o.prec, o.n, o.variant);
   }
 };
 
@@ -105,6 +105,15 @@ struct ed_model {
   // workspace
   int ws_B = 0, ws_L = 0, ws_prec = -1;
   DevBuf X, X2, Abuf, Ybuf, Cpad, Cprune, state, tok, order, uni, qbuf, tvec;
+  // Incremental leading layers (OA-DM, ED_OPT_INCREMENTAL): between two steps ONE token per sequence changes, so
+  // layer k only changes within r_k = r_{k-1} + 2 d_k positions of it.  The first n_inc layers keep their outputs
+  // (Xc[k] = input of layer k, Xc[0] = embedding) and convolution inputs (Cc[k]) from the previous step and
+  // recompute the window of 2 r_k + 1 rows per sequence only.
+  static constexpr int MAX_INC = 4;
+  bool incremental = true;
+  int n_inc = 0;
+  int inc_r[MAX_INC + 1] = {0, 0, 0, 0, 0};  // inc_r[k + 1] = r_k; inc_r[0] = 0 (the changed token itself)
+  DevBuf Xc[MAX_INC + 1], Cc[MAX_INC];
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   bool prune = true;           // ED_OPT_PRUNE
@@ -330,6 +339,25 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   if (prelayout && m->Cprune.p) HIP_TRY(hipMemsetAsync(m->Cprune.p, 0, m->Cprune.bytes, s));
   if (m->plan_s_final > 1) HIP_TRY(need(m->X2, ((size_t)B * L / 2 + 256) * c.d_model * 4));
   HIP_TRY(need(m->partials, (size_t)32 << 20));
+  // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
+  m->n_inc = 0;
+  if (m->incremental && c.timesteps == 0) {
+    int r = 0;
+    for (int k = 0; k < ed_model::MAX_INC && k < c.n_layers - 1; ++k) {
+      r += (c.kernel_size / 2) * m->layers[k].dilation;
+      const long M = 2L * r + 1;
+      const long tiles = ((long)B * M + 255) / 256 * ((c.d_hidden + 319) / 320);
+      if (M * 2 > L || tiles >= m->min_tuned_tiles || m->plan[k].s_out > 1 || m->plan[k + 1].s_out > 1) break;
+      m->inc_r[k + 1] = r;
+      m->n_inc = k + 1;
+    }
+  }
+  for (int k = 0; k <= m->n_inc && m->n_inc > 0; ++k) HIP_TRY(need(m->Xc[k], rows * c.d_model * 4));
+  for (int k = 0; k < m->n_inc; ++k) {
+    const bool fresh = relayout || cbytes > m->Cc[k].bytes;
+    HIP_TRY(need(m->Cc[k], cbytes));
+    if (fresh) HIP_TRY(hipMemsetAsync(m->Cc[k].p, 0, m->Cc[k].bytes, s));
+  }
   if (pitch != m->conv_pitch) grew = true;  // the graphs bake the pitch in
   m->ws_prec = prec;
   m->conv_pitch = pitch;
@@ -340,16 +368,70 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   return ED_OK;
 }
 
-// The block stack (model.py:142-147 + ByteNetBlock).  The fp32 residual stream starts in X; unpruned layers update it
-// in place.  With `pruned` (OA-DM steps only) the trailing layers follow m->plan: they work on compact position sets
-// and a layer that narrows the set writes its output to the other of the two residual buffers.  *x_out receives the
-// buffer that holds the last block's output, L / m->plan_s_final rows per sequence when pruned.
-int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, const float** x_out, hipStream_t s) {
+// Variants of a step: every position with no state kept (forward, D3PM), every position while filling the caches of
+// the incremental layers (first OA-DM step of a call), and the incremental step proper.
+enum { STEP_PLAIN = 0, STEP_FILL = 1, STEP_INCR = 2 };
+
+// One incremental leading layer k (STEP_INCR): the rows within r_{k-1} of the changed position go through
+// LN1 / PFF1 / LN2 into the cached convolution input, the rows within r_k through conv / LN3 / PFF2 into the cached
+// layer output.  Windows have a fixed size and are clamped into [0, L), so the launch shapes do not depend on the
+// position (hipGraph) - rows they cover beyond the changed ones are recomputed to the same values.
+int run_incremental_layer(ed_model* m, int k, int B, int L, int prec, hipStream_t s) {
+  const ed_config& c = m->cfg;
+  const int D = c.d_model, H = c.d_hidden;
+  const bool h = prec == ED_PREC_BF16;
+  const int act = c.activation == 1 ? 1 : 2;
+  const LayerW& w = m->layers[k];
+  const int M_in = 2 * m->inc_r[k] + 1, M_out = 2 * m->inc_r[k + 1] + 1;
+  const int rows_in = B * M_in, rows_out = B * M_out;
+  const int* order = m->order.as<int>();
+  const StepState* st = m->state.as<StepState>();
+  const PosBit win_in = PosBit::window(order, st, m->inc_r[k], L - M_in);
+  const PosBit win_out = PosBit::window(order, st, m->inc_r[k + 1], L - M_out);
+  const float* x_in = m->Xc[k].as<float>();
+  float* x_out = m->Xc[k + 1].as<float>();
+  void* A = m->Abuf.p;
+  void* Y = m->Ybuf.p;
+  const bool y_bf16 = h;
+  int rc;
+  const LnRowMap gather_in{M_in, L, 0, 1, win_in, M_in, 0, PosBit{}};
+  if ((rc = run_ln(m, x_in, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, gather_in, act, s))) return rc;
+  GemmProblem g1{A, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
+  if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
+  const LnRowMap scatter_pad{M_in, M_in, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, win_in};
+  if ((rc = run_ln(m, Y, y_bf16, m->Cc[k].p, h, w.ln2_g, w.ln2_b, rows_in, H, scatter_pad, act, s))) return rc;
+  GemmProblem gc{m->Cc[k].p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
+                 1, rows_out, H, H, c.kernel_size, w.dilation, h, y_bf16};
+  gc.seq_rows = M_out;
+  gc.a_unbounded = true;
+  gc.a_sel = win_out;
+  gc.out_pitch = M_out;
+  if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+  if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, LnRowMap::plain(rows_out), act, s))) return rc;
+  GemmProblem g2{A, 0, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x_out, x_in, 1, rows_out, D, H, 1, 1, h, false};
+  g2.seq_rows = M_out;
+  g2.a_seq_pitch = M_out;
+  g2.out_pitch = L;
+  g2.out_sel = win_out;
+  g2.resid_pitch = L;
+  g2.resid_sel = win_out;
+  return run_gemm(m, g2, ED_K_GEMM1X1, s);
+}
+
+// The block stack (model.py:142-147 + ByteNetBlock).  The fp32 residual stream starts in X (STEP_PLAIN: layers update
+// it in place) or in Xc[0] (STEP_FILL / STEP_INCR: layer k < n_inc reads Xc[k] and writes Xc[k+1], layer n_inc reads
+// Xc[n_inc] and writes X, the rest update X in place).  With `pruned` (OA-DM steps only) the trailing layers follow
+// m->plan: they work on compact position sets and a layer that narrows the set writes its output to the other of the
+// two residual buffers.  *x_out receives the buffer that holds the last block's output, L / m->plan_s_final rows per
+// sequence when pruned.
+int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, int variant, const float** x_out,
+               hipStream_t s) {
   const ed_config& c = m->cfg;
   const int D = c.d_model, H = c.d_hidden, half = c.kernel_size / 2;
   const bool h = prec == ED_PREC_BF16;
   const size_t esz = h ? 2 : 4;
   const int act = c.activation == 1 ? 1 : 2;
+  const int n_inc = variant == STEP_PLAIN ? 0 : m->n_inc;
   float* Xc = m->X.as<float>();
   float* Xo = m->X2.as<float>();
   void* A = m->Abuf.p;
@@ -358,21 +440,36 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, co
   // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
   const bool y_bf16 = h;
   for (int i = 0; i < c.n_layers; ++i) {
+    int rc;
+    if (variant == STEP_INCR && i < n_inc) {
+      if ((rc = run_incremental_layer(m, i, B, L, prec, s))) return rc;
+      continue;
+    }
     const LayerW& w = m->layers[i];
     const LayerPlan pl = pruned ? m->plan[i] : LayerPlan{};
     const int M_in = L / pl.s_in, M_out = L / pl.s_out, in_mul = pl.s_out / pl.s_in;
     const int rows_in = B * M_in, rows_out = B * M_out;
-    int rc;
+    // residual stream of this layer: where it is read and where the layer's output goes
+    const float* x_src = Xc;
+    float* x_dst = Xc;
+    void* cpad = m->Cpad.p;
+    if (i < n_inc) {
+      x_src = m->Xc[i].as<float>();
+      x_dst = m->Xc[i + 1].as<float>();
+      cpad = m->Cc[i].p;
+    } else if (i == n_inc && n_inc > 0) {
+      x_src = m->Xc[i].as<float>();
+    }
     // the 1x1 projections are row-independent: tile them over all rows as one long sequence
-    if ((rc = run_ln(m, Xc, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+    if ((rc = run_ln(m, x_src, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
     GemmProblem g1{A, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
     if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
     long y_pitch;  // rows per sequence of the convolution result in Y
     if (pl.s_in == 1) {
       // every position: per-sequence zero halo in Cpad
-      const LnRowMap to_pad{L, L, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0};
-      if ((rc = run_ln(m, Y, y_bf16, m->Cpad.p, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
-      GemmProblem gc{m->Cpad.p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
+      const LnRowMap to_pad{L, L, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, PosBit{}};
+      if ((rc = run_ln(m, Y, y_bf16, cpad, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
+      GemmProblem gc{cpad, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
                      nullptr, B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
       if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
       y_pitch = L;
@@ -382,7 +479,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, co
       const int dc = w.dilation / pl.s_in;
       const long gap = (long)half * dc, pitch = M_in + gap;
       char* Cc = (char*)m->Cprune.p + (size_t)pl.cp_row * H * esz;
-      const LnRowMap to_compact{M_in, M_in, 0, 1, PosBit{}, pitch, gap};
+      const LnRowMap to_compact{M_in, M_in, 0, 1, PosBit{}, pitch, gap, PosBit{}};
       if ((rc = run_ln(m, Y, y_bf16, Cc, h, w.ln2_g, w.ln2_b, rows_in, H, to_compact, act, s))) return rc;
       GemmProblem gc{Cc, 0, gap, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
                      1, (int)(B * pitch - gap), H, H, c.kernel_size, dc, h, y_bf16};
@@ -391,10 +488,15 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, co
     }
     // positions kept for the next layer: every in_mul-th row, starting at the row the fill position selects
     PosBit sel;
-    if (in_mul > 1) sel = PosBit{m->order.as<int>(), m->state.as<StepState>(), __builtin_ctz(pl.s_in), in_mul - 1};
-    const LnRowMap keep{M_out, y_pitch, 0, in_mul, sel, M_out, 0};
+    if (in_mul > 1) {
+      sel.order = m->order.as<int>();
+      sel.state = m->state.as<StepState>();
+      sel.shift = __builtin_ctz(pl.s_in);
+      sel.mask = in_mul - 1;
+    }
+    const LnRowMap keep{M_out, y_pitch, 0, in_mul, sel, M_out, 0, PosBit{}};
     if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, keep, act, s))) return rc;
-    GemmProblem g2{A, rows_out, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, Xc, Xc, 1, rows_out, D, H, 1, 1, h, false};
+    GemmProblem g2{A, rows_out, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x_dst, x_src, 1, rows_out, D, H, 1, 1, h, false};
     if (in_mul > 1) {
       g2.out = Xo;
       g2.resid_mul = in_mul;
@@ -409,12 +511,20 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, co
   return ED_OK;
 }
 
-int run_embed(ed_model* m, const int64_t* tokens, const int64_t* tvec, int B, int L, hipStream_t s) {
+int run_embed(ed_model* m, const int64_t* tokens, const int64_t* tvec, int B, int L, int variant, hipStream_t s) {
   const ed_config& c = m->cfg;
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
+  float* x0 = variant != STEP_PLAIN && m->n_inc > 0 ? m->Xc[0].as<float>() : m->X.as<float>();
+  if (variant == STEP_INCR && m->n_inc > 0) {
+    // only the row the previous step filled differs from the cached embedding
+    LAUNCH_TRY(launch_embed_gather_rows(tokens, m->emb_table.as<float>(), x0, B, L, c.d_model, c.n_tokens,
+                                        PosBit::window(m->order.as<int>(), m->state.as<StepState>(), 0, L - 1), s));
+    LAUNCH_TRY(pr.end(ED_K_EMBED, 0.0, (double)B * (8 + c.d_model * 4.0)));
+    return ED_OK;
+  }
   if (c.timesteps == 0)
-    LAUNCH_TRY(launch_embed_gather(tokens, m->emb_table.as<float>(), m->X.as<float>(), B * L, c.d_model, c.n_tokens, s));
+    LAUNCH_TRY(launch_embed_gather(tokens, m->emb_table.as<float>(), x0, B * L, c.d_model, c.n_tokens, s));
   else
     LAUNCH_TRY(launch_embed(tokens, tvec, m->state.as<StepState>(), m->emb, m->pe, c.timesteps, m->up_w, m->up_b,
                             m->X.as<float>(), B * L, B, c.d_model, c.d_embed, c.n_tokens, s));
@@ -434,13 +544,15 @@ int check_shape(const ed_model* m, int B, int L, int prec) {
 enum { MODE_OADM = 0, MODE_D3PM = 1 };
 
 // One sampling step on the model-owned buffers (tok/order/uni/qbuf/state).
-int run_step(ed_model* m, int mode, int B, int L, int n, int prec, float* probs, double* post, hipStream_t s) {
+int run_step(ed_model* m, int mode, int variant, int B, int L, int n, int prec, float* probs, double* post,
+             hipStream_t s) {
   const ed_config& c = m->cfg;
   int rc;
-  if ((rc = run_embed(m, m->tok.as<int64_t>(), nullptr, B, L, s))) return rc;
+  if (m->n_inc == 0) variant = STEP_PLAIN;
+  if ((rc = run_embed(m, m->tok.as<int64_t>(), nullptr, B, L, variant, s))) return rc;
   const bool pruned = mode == MODE_OADM && m->plan_s_final > 1;
   const float* xf = nullptr;
-  if ((rc = run_blocks(m, B, L, prec, nullptr, pruned, &xf, s))) return rc;
+  if ((rc = run_blocks(m, B, L, prec, nullptr, pruned, variant, &xf, s))) return rc;
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
   if (mode == MODE_OADM) {
@@ -460,10 +572,10 @@ int run_step(ed_model* m, int mode, int B, int L, int n, int prec, float* probs,
   return ED_OK;
 }
 
-int get_graph(ed_model* m, int mode, int B, int L, int n, int prec, float* probs, double* post,
+int get_graph(ed_model* m, int mode, int variant, int B, int L, int n, int prec, float* probs, double* post,
               hipGraphExec_t* out) {
   // trace buffers are caller-owned: graphs are only cached for the trace-free form
-  const GraphKey key{mode, B, L, prec, n};
+  const GraphKey key{mode, B, L, prec, n, variant};
   auto it = m->graphs.find(key);
   if (it != m->graphs.end()) {
     *out = it->second;
@@ -473,7 +585,7 @@ int get_graph(ed_model* m, int mode, int B, int L, int n, int prec, float* probs
   HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
   const bool was = m->probing_now;
   m->probing_now = false;
-  int rc = run_step(m, mode, B, L, n, prec, probs, post, m->cap_stream);
+  int rc = run_step(m, mode, variant, B, L, n, prec, probs, post, m->cap_stream);
   m->probing_now = was;
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
@@ -493,19 +605,24 @@ int get_graph(ed_model* m, int mode, int B, int L, int n, int prec, float* probs
 
 int run_loop(ed_model* m, int mode, int B, int L, int n, int n_steps, int prec, int use_graph, float* probs,
              double* post, hipStream_t s) {
-  hipGraphExec_t exec = nullptr;
   const bool traced = probs != nullptr || post != nullptr;
+  // OA-DM with incremental leading layers: the first step of a call fills their caches, the others update them
+  const bool inc = mode == MODE_OADM && m->n_inc > 0;
+  hipGraphExec_t exec_first = nullptr, exec_rest = nullptr;
   if (use_graph && !traced) {
-    int rc = get_graph(m, mode, B, L, n, prec, nullptr, nullptr, &exec);
+    int rc = get_graph(m, mode, inc ? STEP_FILL : STEP_PLAIN, B, L, n, prec, nullptr, nullptr, &exec_first);
     if (rc) return rc;
+    exec_rest = exec_first;
+    if (inc && n_steps > 1 && (rc = get_graph(m, mode, STEP_INCR, B, L, n, prec, nullptr, nullptr, &exec_rest))) return rc;
   }
   for (int step = 0; step < n_steps; ++step) {
     const bool probe = m->probe_every > 0 && (step % m->probe_every) == 0;
+    hipGraphExec_t exec = step == 0 ? exec_first : exec_rest;
     if (exec && !probe) {
       HIP_TRY(hipGraphLaunch(exec, s));
     } else {
       m->probing_now = probe;
-      int rc = run_step(m, mode, B, L, n, prec, probs, post, s);
+      int rc = run_step(m, mode, !inc ? STEP_PLAIN : (step == 0 ? STEP_FILL : STEP_INCR), B, L, n, prec, probs, post, s);
       m->probing_now = false;
       if (rc) return rc;
     }
@@ -686,10 +803,10 @@ int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* ti
   HIP_TRY(hipSetDevice(m->device));
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   m->probing_now = m->probe_every > 0;
-  rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, s);
+  rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, STEP_PLAIN, s);
   if (!rc && acts_dev)
     HIP_TRY(hipMemcpyAsync(acts_dev, m->X.p, (size_t)B * L * m->cfg.d_model * 4, hipMemcpyDeviceToDevice, s));
-  if (!rc) rc = run_blocks(m, B, L, precision, acts_dev, false, nullptr, s);
+  if (!rc) rc = run_blocks(m, B, L, precision, acts_dev, false, STEP_PLAIN, nullptr, s);
   if (!rc) {
     Probe pr(m, s);
     LAUNCH_TRY(pr.begin());
@@ -838,6 +955,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_SPLIT_TARGET:
       if (value < 0 || value > 4096) return fail(ED_EINVAL, "ED_OPT_SPLIT_TARGET must be in [0, 4096]");
       m->split_target = value;
+      break;
+    case ED_OPT_INCREMENTAL:
+      if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_INCREMENTAL takes 0 or 1");
+      m->incremental = value != 0;
       break;
     case ED_OPT_MIN_TUNED_TILES:
       if (value < 0) return fail(ED_EINVAL, "ED_OPT_MIN_TUNED_TILES must be >= 0");

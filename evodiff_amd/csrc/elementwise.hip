@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const void* __restrict__ in
   load_row<NCH, IN_BF16>(in, irow, C, lane, v);
   if constexpr (OUT_BF16) normalize_row_onepass<NCH>(v, C, lane);
   else normalize_row<NCH>(v, C, lane);
-  const long orow = map.out_row0 + seq * map.out_pitch + m;
+  const long orow = map.out_row0 + seq * map.out_pitch + m + map.out_sel.get();
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int idx = (c * 64 + lane) * 4;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void ln_act_fast_kernel(const void* __restrict
   const unsigned rps = (unsigned)map.rows_per_seq;
   const unsigned seq = (unsigned)row / rps, m = (unsigned)row - seq * rps;
   const long irow = map.in_row0 + (long)seq * map.in_pitch + (long)m * map.in_mul + map.in_sel.get();
-  const long orow = map.out_row0 + (long)seq * map.out_pitch + m;
+  const long orow = map.out_row0 + (long)seq * map.out_pitch + m + map.out_sel.get();
   // channel index of value slot k (a multiple of 4 slots shares one 16-byte piece of gamma / beta)
   auto chan = [&](int k) { return k < NC8 * 8 ? ((k >> 3) * 64 + lane) * 8 + (k & 7) : NC8 * 512 + (((k - NC8 * 8) >> 2) * 64 + lane) * 4 + (k & 3); };
 
@@ -512,6 +512,24 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
   if (E > 16 || rows <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, stream, tokens, tvec, state, emb, pe, n_timesteps,
                      up_w, up_b, X, rows, B, D, E, n_tokens);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void embed_gather_rows_kernel(const int64_t* __restrict__ tokens,
+                                                               const float* __restrict__ table, float* __restrict__ X,
+                                                               int L, int D, int n_tokens, PosBit sel) {
+  const long row = (long)blockIdx.x * L + sel.get();
+  long tok = tokens[row];
+  if (tok < 0 || tok >= n_tokens) tok = n_tokens - 1;
+  const float4* src = (const float4*)(table + tok * D);
+  float4* dst = (float4*)(X + row * D);
+  for (int c = threadIdx.x; c < D / 4; c += 64) dst[c] = src[c];
+}
+
+hipError_t launch_embed_gather_rows(const int64_t* tokens, const float* table, float* X, int B, int L, int D,
+                                    int n_tokens, PosBit sel, hipStream_t stream) {
+  if (D % 4 != 0 || B <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_gather_rows_kernel, dim3(B), dim3(64), 0, stream, tokens, table, X, L, D, n_tokens, sel);
   return hipGetLastError();
 }
 

@@ -331,7 +331,7 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
 // [a_row0 - halo, a_row0 + ceil(L/256)*256 + halo) of every sequence are readable, with halo =
 // (ntaps/2)*dilation, and rows outside [0, L) hold zeros whenever ntaps > 1.
 bool gemm_bf16_supported(const GemmProblem& p) {
-  if (!p.a_bf16 || p.K % BK != 0 || p.K < BK) return false;
+  if (!p.a_bf16 || p.K % BK != 0 || p.K < BK || p.seq_rows > 0) return false;
   if (p.N % 320 != 0 && p.N % 256 != 0) return false;
   if ((long)p.B * p.L < BM) return false;               // less than one 256-row tile: generic kernel
   if ((long)p.K * 2 * 64 >= (1L << 31)) return false;   // per-lane DMA offsets are 32-bit

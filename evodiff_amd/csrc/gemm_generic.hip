@@ -47,8 +47,16 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
 
   // contiguous range of taps that touch this tile at all
   int tap_lo = 0, tap_hi = g.ntaps - 1;
-  while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
-  while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
+  if (!g.a_unbounded) {
+    while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
+    while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
+  }
+  // row groups: this loader thread's A row without the tap shift, and whether it exists at all
+  long a_row_grouped = 0;
+  if (g.seq_rows > 0) {
+    const unsigned R = (unsigned)(l0 + lrow), bs = R / (unsigned)g.seq_rows, ls = R - bs * (unsigned)g.seq_rows;
+    a_row_grouped = (long)bs * g.a_seq_pitch + g.a_row0 + g.a_sel.get() + ls;
+  }
   int it_begin = tap_lo * ksteps, it_end = (tap_hi + 1) * ksteps;
   if (g.ksplit > 1) {  // this workgroup's share of the K loop
     const int chunk = (it_end - it_begin + g.ksplit - 1) / g.ksplit;
@@ -66,11 +74,14 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   auto gload = [&](int it, uint4 (&a4)[4], uint4 (&b4)[4]) {
     const int tap = it / ksteps;
     const int ks = it - tap * ksteps;
-    const int l = l0 + lrow + (tap - half_taps) * g.dilation;
+    const int shift = (tap - half_taps) * g.dilation;
+    const int l = l0 + lrow + shift;
     const uint4 z = make_uint4(0, 0, 0, 0);
     const bool k_on = !(last_half_empty && ks == ksteps - 1 && lhalf == 1);
-    if (k_on && l >= 0 && l < g.L) {
-      const uint4* p = (const uint4*)(Abase + (((long)b * g.a_seq_pitch + g.a_row0 + l) * g.K + (long)ks * KSTEP) * ESZ + lhalf * 64);
+    const bool row_on = g.seq_rows > 0 ? (l0 + lrow < g.L && (g.a_unbounded || (l >= 0 && l < g.L))) : (l >= 0 && l < g.L);
+    const long a_row = g.seq_rows > 0 ? a_row_grouped + shift : (long)b * g.a_seq_pitch + g.a_row0 + l;
+    if (k_on && row_on) {
+      const uint4* p = (const uint4*)(Abase + (a_row * g.K + (long)ks * KSTEP) * ESZ + lhalf * 64);
 #pragma unroll
       for (int i = 0; i < 4; ++i) a4[i] = p[i];
     } else {
@@ -166,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     return;
   }
   const int rsel = RESID ? g.resid_sel.get() : 0;
+  const int osel = g.seq_rows > 0 ? g.out_sel.get() : 0;
   // epilogue: C[row][col] with col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -178,9 +190,15 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       for (int r = 0; r < 16; ++r) {
         const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (l >= g.L) continue;
-        const long o = ((long)b * g.L + l) * g.N + n;
+        long o = ((long)b * g.L + l) * g.N + n;
+        long ro = (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + n;
+        if (g.seq_rows > 0) {
+          const unsigned bs = (unsigned)l / (unsigned)g.seq_rows, ls = (unsigned)l - bs * (unsigned)g.seq_rows;
+          o = ((long)bs * g.out_pitch + osel + ls) * g.N + n;
+          ro = ((long)bs * g.resid_pitch + (long)ls * g.resid_mul + rsel) * g.N + n;
+        }
         float v = acc[i][j][r] + bias;
-        if constexpr (RESID) v += g.resid[(((long)b * g.L + l) * g.resid_mul + rsel) * g.N + n];
+        if constexpr (RESID) v += g.resid[ro];
         if constexpr (OUT_BF16) ((bf16_t*)g.out)[o] = f32_to_bf16_bits(v);
         else ((float*)g.out)[o] = v;
       }
@@ -195,9 +213,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmProblem g) {
   if (q >= quads) return;
   const long e = q * 4, r = e / g.N;
   const int n = (int)(e - r * g.N);
+  long orow = r, rrow = r * g.resid_mul + g.resid_sel.get();
+  if (g.seq_rows > 0) {
+    const long bs = r / g.seq_rows, ls = r - bs * g.seq_rows;
+    orow = bs * g.out_pitch + g.out_sel.get() + ls;
+    rrow = bs * g.resid_pitch + ls * g.resid_mul + g.resid_sel.get();
+  }
   float4 s = *(const float4*)(g.bias + n);
   if (g.resid) {
-    const float4 x = *(const float4*)(g.resid + (r * g.resid_mul + g.resid_sel.get()) * g.N + n);
+    const float4 x = *(const float4*)(g.resid + rrow * g.N + n);
     s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
   }
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -210,9 +234,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GemmProblem g) {
     uint2 pk;
     pk.x = (unsigned)f32_to_bf16_bits(s.x) | ((unsigned)f32_to_bf16_bits(s.y) << 16);
     pk.y = (unsigned)f32_to_bf16_bits(s.z) | ((unsigned)f32_to_bf16_bits(s.w) << 16);
-    *(uint2*)((bf16_t*)g.out + e) = pk;
+    *(uint2*)((bf16_t*)g.out + orow * g.N + n) = pk;
   } else {
-    *(float4*)((float*)g.out + e) = s;
+    *(float4*)((float*)g.out + orow * g.N + n) = s;
   }
 }
 
@@ -232,6 +256,7 @@ hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream) {
   if (p.K % kstep != 0 || p.B <= 0 || p.L <= 0 || p.N <= 0 || (p.ntaps & 1) == 0) return hipErrorInvalidValue;
   if (p.resid && p.out_bf16) return hipErrorInvalidValue;
   if (p.ksplit < 1 || (p.ksplit > 1 && !p.partial)) return hipErrorInvalidValue;
+  if (p.seq_rows > 0 && (p.B != 1 || p.L % p.seq_rows != 0)) return hipErrorInvalidValue;
   dim3 grid((p.N + BN - 1) / BN, (unsigned)(p.B * ((p.L + BM - 1) / BM)), (unsigned)p.ksplit);
   dim3 block(256);
 #define ED_LAUNCH(BF, OB, RS) hipLaunchKernelGGL((gemm_generic_kernel<BF, OB, RS>), grid, block, 0, stream, p)

@@ -22,15 +22,29 @@ struct StepState {
   int t_start;  // D3PM: t of step 0; the current t is t_start - step
 };
 
-// Device-side selector: bits [shift, shift + log2(mask + 1)) of order[state->step], the position the current
-// OA-DM step fills (order == nullptr: always 0).  Lets row maps that depend on that position live inside a
-// captured graph.
+// Device-side row selector (order == nullptr: always 0); lets row maps that depend on the OA-DM positions live
+// inside a captured graph.
+//  - bit field (maxstart < 0): bits [shift, shift + log2(mask + 1)) of order[step], the position the step fills;
+//  - window (maxstart >= 0): first row of the window of rows that changed since the previous step, i.e. that lie
+//    within `radius` of order[step - 1] (the position the previous step filled), clamped to [0, maxstart].
 struct PosBit {
   const int* order = nullptr;
   const StepState* state = nullptr;
   int shift = 0;
   int mask = 0;
-  __device__ __forceinline__ int get() const { return order ? (order[state->step] >> shift) & mask : 0; }
+  int radius = 0;
+  int maxstart = -1;
+  __device__ __forceinline__ int get() const {
+    if (!order) return 0;
+    if (maxstart < 0) return (order[state->step] >> shift) & mask;
+    const int s = order[state->step - 1] - radius;
+    return s < 0 ? 0 : (s > maxstart ? maxstart : s);
+  }
+  static PosBit window(const int* order, const StepState* state, int radius, int maxstart) {
+    PosBit p;
+    p.order = order; p.state = state; p.radius = radius; p.maxstart = maxstart;
+    return p;
+  }
 };
 
 // One implicit-GEMM problem: out[b*L + l][n] = bias[n] (+ resid) + sum_{tap,k} A[row(b, l + off(tap))][k] * W[tap][n][k]
@@ -48,6 +62,15 @@ struct GemmProblem {
   bool out_bf16;        // element type of out (resid != nullptr requires fp32 out)
   int resid_mul = 1;    // the residual of output row R is row R * resid_mul + resid_sel.get() of `resid`
   PosBit resid_sel;     //   (resid_mul > 1: every resid_mul-th row of a longer buffer; then resid must not alias out)
+  // Row groups (generic kernel and reduction only; the tuned kernels refuse such problems).  seq_rows > 0: the problem
+  // is flat (B = 1) and its row R belongs to sequence b = R / seq_rows at offset l = R % seq_rows, with
+  //   A row   = b * a_seq_pitch + a_row0 + a_sel + l (+ tap shift), read without bounds checks when a_unbounded
+  //             (the rows around the window are real data or real zero padding),
+  //   out row = b * out_pitch + out_sel + l,   resid row = b * resid_pitch + l * resid_mul + resid_sel.
+  int seq_rows = 0;
+  bool a_unbounded = false;
+  PosBit a_sel, out_sel;
+  long out_pitch = 0, resid_pitch = 0;
   int ksplit = 1;       // generic kernel only: the K loop is cut into ksplit ranges (grid.z); range z writes its raw fp32
   float* partial = nullptr;  //   sums to partial[z][B*L][N] and launch_reduce_partials adds them up in a fixed order
   long long* stamps = nullptr;  // diagnostics (ablate == 7): per tile {shader cycles, 100-MHz ticks} of the K loop
@@ -77,15 +100,20 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
 hipError_t launch_embed_gather(const int64_t* tokens, const float* table, float* X, int rows, int D, int n_tokens,
                                hipStream_t stream);
 
+// X[b*L + sel] = table[tokens[b*L + sel]] for every sequence b: the one row per sequence that changed.
+hipError_t launch_embed_gather_rows(const int64_t* tokens, const float* table, float* X, int B, int L, int D,
+                                    int n_tokens, PosBit sel, hipStream_t stream);
+
 // Row maps of the LayerNorm kernel: logical row r = (b, m), m < rows_per_seq, is read from row
-// in_row0 + b*in_pitch + m*in_mul + in_sel.get() and written to row out_row0 + b*out_pitch + m.
+// in_row0 + b*in_pitch + m*in_mul + in_sel.get() and written to row out_row0 + b*out_pitch + m + out_sel.get().
 struct LnRowMap {
   int rows_per_seq;
   long in_pitch, in_row0;
   int in_mul;
   PosBit in_sel;
   long out_pitch, out_row0;
-  static LnRowMap plain(int rows) { return LnRowMap{rows, rows, 0, 1, PosBit{}, rows, 0}; }
+  PosBit out_sel;  // added to the output row
+  static LnRowMap plain(int rows) { return LnRowMap{rows, rows, 0, 1, PosBit{}, rows, 0, PosBit{}}; }
 };
 // out = act(LayerNorm(in)) row-wise; in, out fp32/bf16 rows of C channels.  act: 0 none, 1 exact GELU, 2 ReLU.
 hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
