@@ -9,12 +9,12 @@ L=256 (256 denoiser forwards + draws) on every rank, followed by the all-gather 
 N > 1.  Weights are synthetic (reference-constructor default init under seed 0), inputs are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel is the windowed dilated convolution (conv_window_kernel, dilation <= 16: 41 of a
-step's 340 launches, 28 % of its time).  Its launches are timed live with HIP-event pairs on the launch stream on
+roofline: the dominant kernel is the windowed dilated convolution (conv_window_kernel: the convolution of every
+block at L <= 256, 46 % of a step's time).  Its launches are timed live with HIP-event pairs on the launch stream on
 every 32nd diffusion step inside the timed region; achieved = algorithmic FLOPs of those launches (in-range taps
 only) / their summed duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.  traffic = memory-side
-bytes of one such launch from the committed PMC passes (profiles/, tools/pmc_traffic.sh), for the default
-config only.  cpu_baseline: the CPU oracle (a port of the reference's PyTorch path) timed on this host for
+bytes of one such launch (dilation 1) from the committed PMC passes (profiles/, tools/pmc_traffic.sh), for the
+default config only.  cpu_baseline: the CPU oracle (a port of the reference's PyTorch path) timed on this host for
 a bounded sample.
 """
 import argparse
@@ -174,7 +174,7 @@ def main():
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world} (sequence sharding)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": measured_traffic(args),
-                         "kernel": "conv_window_kernel (dilated k=5 convolution, dilation <= 16)",
+                         "kernel": "conv_window_kernel (dilated k=5 convolution, activation window resident in LDS)",
                          "launches_timed": conv["launches"],
                          "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
                          "flops_per_launch": conv["flops"] / max(conv["launches"], 1)},
@@ -184,7 +184,7 @@ def main():
             "step_roofline": {"flops_per_sequence": f_eff, "achieved": f_eff * world * B * args.steps / elapsed / 1e12,
                               "unit": "TFLOP/s", "frac": f_eff * world * B * args.steps / elapsed / 1e12 / peak,
                               "note": "denominator counts every position of every block; dependency-cone pruning "
-                                      "skips ~10 % of it in the OA-DM path"},
+                                      "and the incremental leading layers skip ~15 % of it in the OA-DM path"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L)
