@@ -17,7 +17,12 @@
 // output channels of one position (8/16-byte stores in the epilogue).
 //
 // LDS: 2 windows x 320 rows x 128 B + 2 weight stages x BN rows x 128 B = 160 KiB at BN = 320: the window is
-// limited to 320 rows, i.e. dilation <= 16 (five of the eight dilations of a ByteNet cycle).
+// limited to 320 rows, i.e. dilation <= 16 (five of the eight dilations of a ByteNet cycle) in general.
+//
+// Whole-sequence form (L <= 256: one tile per sequence; dilation 32, 64, 128): everything outside the tile is zero
+// padding, so the window is the sequence itself (+ 32 rows either side at dilation 32).  Taps that no row of the
+// tile can reach leave the K loop, and a wave skips a tap that moves all of its 64 rows into the padding (it still
+// issues its share of the copies); its SIMD partner then has the matrix pipe to itself.  See window_plan().
 #include "kernels.hpp"
 
 #include <type_traits>

@@ -15,8 +15,7 @@ dev = torch.device("cuda", 0)
 B, L, n = 64, 256, 32
 order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
 uni = torch.rand((n, B), device=dev)
-for prune, tiles, split in ((0, 96, 512), (1, 96, 0), (1, 96, 256), (1, 96, 512), (1, 96, 1024), (1, 96, 2048), (1, 130, 1024),
-                            (1, 40, 1024)):
+for prune, tiles, split in ((1, 40, 512), (1, 24, 512), (1, 64, 512), (1, 40, 128), (1, 40, 2048), (0, 40, 512)):
     m.set_option("prune", prune)
     m.set_option("min_tuned_tiles", tiles)
     m.set_option("split_target", split)
