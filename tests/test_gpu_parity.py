@@ -441,6 +441,51 @@ def test_38m_config5_full_size_batch_invariance(dev):
     assert np.abs(p_got[0].cpu().numpy() - p_ref.numpy()).max() < 5e-2
 
 
+def test_conditional_callers_against_oracle(dev):
+    """inpaint_simple / generate_scaffold are the OA-DM loop with a partially filled start and an
+    order over the masked positions (B = 1: the weight-streaming regime; repeated positions when batch_size > 1).
+    fp32 tokens must equal the oracle's loop on the same start, order and uniforms."""
+    from evodiff_amd.conditional_generation import generate_scaffold, get_intervals, inpaint_simple
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oadm_trace.npz"))
+    oracle = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    m = product_model(oracle, TINY_WIDE, precision="fp32")
+    tok = Tokenizer()
+    rng = np.random.default_rng(7)
+    # --- inpainting a region of a 120-residue sequence
+    seq = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), 120))
+    s0, s1 = 37, 71
+    order = rng.permutation(np.arange(s0, s1))
+    uni = torch.from_numpy(rng.random((len(order), 1), dtype=np.float32))
+    start = torch.tensor(tok.tokenizeMSA(seq[:s0] + "#" * (s1 - s0) + seq[s1:]), dtype=torch.long).unsqueeze(0)
+    trace = []
+    ref = R.generate_oaardm_ref(oracle, 120, 1, order, uni, trace=trace, start=start)
+    sample, full, region = inpaint_simple(m, seq, s0, s1, tokenizer=tok, device=dev, order=order, uniforms=uni)
+    margins = np.array([float(t["margin"].min()) for t in trace])
+    assert margins.min() > DRAW_MARGIN_FP32, "seed gives a boundary-ambiguous draw; pick another"
+    assert np.array_equal(sample.cpu().numpy(), ref[0].numpy())
+    assert full[:s0] == seq[:s0] and full[s1:] == seq[s1:] and region == full[s0:s1] and "#" not in full
+    # --- scaffolding a motif, two sequences: every masked position is visited twice (reference quirk)
+    motif, scaffold_length, new_start = "HELLKAGH", 40, 11
+    L = scaffold_length + len(motif)
+    masked = np.array([p for p in range(L) if not (new_start <= p < new_start + len(motif))])
+    order = rng.permutation(np.concatenate([masked, masked]))
+    uni = torch.from_numpy(rng.random((len(order), 2), dtype=np.float32))
+    start = torch.full((2, L), R.MASK_ID, dtype=torch.long)
+    start[:, new_start:new_start + len(motif)] = torch.tensor(tok.tokenize((motif,)))
+    trace = []
+    ref = R.generate_oaardm_ref(oracle, L, 2, order, uni, trace=trace, start=start)
+    strings, starts, ends = generate_scaffold(m, motif, scaffold_length, tok, batch_size=2, device=dev,
+                                              new_start=new_start, order=order, uniforms=uni)
+    assert (starts, ends) == ([new_start], [new_start + len(motif) - 1])
+    assert all(s[new_start:new_start + len(motif)] == motif and "#" not in s for s in strings)
+    assert min(float(t["margin"].min()) for t in trace) > DRAW_MARGIN_FP32, "seed gives a boundary-ambiguous draw"
+    assert strings == [tok.untokenize(r) for r in ref]
+    assert get_intervals([3, 4, 5, 9, 10, 20, 21]) == ([3, 9, 20], [5, 10, 21])
+
+
 def test_errors_are_raised_not_faults(dev):
     from evodiff_amd import _lib
     oracle = R.build_model(TINY, None, 1)
