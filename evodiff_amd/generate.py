@@ -88,3 +88,21 @@ def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, batch_size=3, 
     untokenized = _strings(tokenizer, sample)
     print("final seq", untokenized)
     return sample, untokenized
+
+
+def write_generated(string, out_fpath, count=0):
+    """The two files ``evodiff/generate.py:140-145`` writes after sampling: ``generated_samples_string.csv`` (one
+    sequence per line) and ``generated_samples_string.fasta`` (records ``>SEQUENCE_<count+i>``).  ``string`` is the
+    reference's list of per-call string lists (``[[seq], [seq], ...]``: element 0 of each entry is written); a flat
+    list of sequences is accepted as well.  ``out_fpath`` is a directory prefix ending in '/' as there."""
+    import os
+    rows = [s if isinstance(s, str) else s[0] for s in string]
+    if out_fpath and not os.path.exists(out_fpath):
+        os.makedirs(out_fpath)
+    with open(out_fpath + 'generated_samples_string.csv', 'w') as f:
+        for _s in rows:
+            f.write(_s + "\n")
+    with open(out_fpath + 'generated_samples_string.fasta', 'w') as f:
+        for i, _s in enumerate(rows):
+            f.write(">SEQUENCE_" + str(count + i) + "\n" + str(_s) + "\n")
+    return rows

@@ -113,3 +113,20 @@ def test_d3pm_loader_tuple():
     assert tuple(Q_prod.shape) == (500, 26, 26) and collater.num_timesteps == 500
     np.testing.assert_allclose(Q_t.sum(dim=1).numpy(), 1.0, atol=1e-6)      # columns sum to one
     assert len(pretrained.D3PM_BLOSUM_38M(random_init=True)) == 4
+
+
+def test_write_generated_matches_reference_file_formats(tmp_path):
+    """generate.py:140-145: csv = one sequence per line; fasta = >SEQUENCE_<count+i> records."""
+    from evodiff_amd.generate import write_generated
+    out = str(tmp_path) + "/run/"
+    rows = write_generated([["ACDE"], ["MKV", "ignored"], "WYY"], out, count=7)
+    assert rows == ["ACDE", "MKV", "WYY"]
+    assert open(out + "generated_samples_string.csv").read() == "ACDE\nMKV\nWYY\n"
+    assert open(out + "generated_samples_string.fasta").read() == (
+        ">SEQUENCE_7\nACDE\n>SEQUENCE_8\nMKV\n>SEQUENCE_9\nWYY\n")
+
+
+def test_get_intervals_of_motif_positions():
+    from evodiff_amd.conditional_generation import get_intervals
+    assert get_intervals([3, 4, 5, 9, 10, 20, 21]) == ([3, 9, 20], [5, 10, 21])
+    assert get_intervals([4, 7], single_res_domain=True) == ([4, 7], [4, 7])
