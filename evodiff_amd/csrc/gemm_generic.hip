@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   const char* Wbase = (const char*)g.W;
   const int nrow = n0 + lrow;
 
-  // Two register sets: the loads of K-step it+2 are issued as soon as set (it & 1) has been written to LDS, so every
-  // load has two full steps to return (small problems run few workgroups per CU and are latency-bound otherwise).
-  uint4 ra[2][4], rb[2][4];
+  // PF register sets: the loads of K-step it+PF are issued as soon as the set of step it has been written to LDS, so
+  // every load has PF full steps to return (small problems run few workgroups per CU, stream cold weights from HBM
+  // and are latency-bound otherwise).
+  constexpr int PF = 4;
+  uint4 ra[PF][4], rb[PF][4];
   auto gload = [&](int it, uint4 (&a4)[4], uint4 (&b4)[4]) {
     const int tap = it / ksteps;
     const int ks = it - tap * ksteps;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = b4[i];
     }
     __syncthreads();
-    if (it + 2 < it_end) gload(it + 2, a4, b4);
+    if (it + PF < it_end) gload(it + PF, a4, b4);
     // Each lane takes 32 contiguous bytes of its row at byte 64*h + 32*fh of the slice.  The k order seen by the
     // MFMA is a permutation of the true k, identical for A and B, so the sum over k is unchanged.
 #pragma unroll
@@ -153,11 +155,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     __syncthreads();
   };
 
-  if (it_begin < it_end) gload(it_begin, ra[0], rb[0]);
-  if (it_begin + 1 < it_end) gload(it_begin + 1, ra[1], rb[1]);
-  for (int it = it_begin; it < it_end; it += 2) {
-    step(it, ra[0], rb[0]);
-    if (it + 1 < it_end) step(it + 1, ra[1], rb[1]);
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (it_begin + u < it_end) gload(it_begin + u, ra[u], rb[u]);
+  for (int it = it_begin; it < it_end; it += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (it + u < it_end) step(it + u, ra[u], rb[u]);
   }
 
   if (g.ksplit > 1) {  // raw partial sums; bias, residual and rounding happen in the reduction
