@@ -117,7 +117,7 @@ struct ed_model {
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   bool prune = true;           // ED_OPT_PRUNE
-  int min_tuned_tiles = 40;    // ED_OPT_MIN_TUNED_TILES
+  int min_tuned_tiles = 70;    // ED_OPT_MIN_TUNED_TILES
   std::vector<LayerPlan> plan; // per layer, for the current (B, L)
   int plan_s_final = 1;        // stride of the position set the last block produces
   long conv_pitch = 0, conv_row0 = 0;  // layout of Cpad: [B][conv_pitch][d_hidden], position 0 at row conv_row0
