@@ -9,7 +9,8 @@ m, _, tok, _ = OA_DM_640M(random_init=True)
 m.precision = "bf16"
 m.use_graph = False
 dev = torch.device("cuda", 0)
-B, L, n = 64, 256, 4
+import os
+B, L, n = int(os.environ.get("TRACE_B", "64")), 256, 4
 order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
 uni = torch.rand((n, B), device=dev)
 sample = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
