@@ -40,34 +40,41 @@ __device__ __forceinline__ float gelu_bf16_grade(float x) {
 // ---------------------------------------------------------------------------------------------------
 // embed: evodiff/model.py:131-140
 // ---------------------------------------------------------------------------------------------------
+// One thread per channel keeps its row of the up-projection (E <= 16 weights) in registers and walks ROWS_PER_BLOCK
+// rows: the weights are read once per block instead of once per row, the stores are coalesced along the channels.
+constexpr int EMBED_ROWS_PER_BLOCK = 32;
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const int64_t* tvec,
                                                     const StepState* state, const float* __restrict__ emb,
                                                     const float* __restrict__ pe, int n_timesteps,
                                                     const float* __restrict__ up_w, const float* __restrict__ up_b,
                                                     float* __restrict__ X, int rows, int B, int D, int E,
                                                     int n_tokens) {
-  const int row = blockIdx.x;
-  if (row >= rows) return;
-  long tok = tokens[row];
-  if (tok < 0 || tok >= n_tokens) tok = n_tokens - 1;  // host validates; never index out of the table
-  float e[16];
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const bool c_on = c < D;
+  float w[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) e[j] = j < E ? emb[tok * E + j] : 0.f;
-  if (pe != nullptr) {
-    // quirk Q1 (model.py:136-137): expand(L,B,E).reshape(B,L,E) => row r receives pe[y[r % B]]
-    long t = tvec ? tvec[row % B] : (long)(state->t_start - state->step);
-    if (t < 0) t = 0;
-    if (t >= n_timesteps) t = n_timesteps - 1;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (j < E) e[j] = pe[t * E + j] + e[j];
-  }
-  for (int c = threadIdx.x; c < D; c += 256) {
+  for (int j = 0; j < 16; ++j) w[j] = (c_on && j < E) ? up_w[c * E + j] : 0.f;
+  const float bias = c_on ? up_b[c] : 0.f;
+  const int row_end = min(rows, (int)(blockIdx.x + 1) * EMBED_ROWS_PER_BLOCK);
+  for (int row = blockIdx.x * EMBED_ROWS_PER_BLOCK; row < row_end; ++row) {
+    long tok = tokens[row];
+    if (tok < 0 || tok >= n_tokens) tok = n_tokens - 1;  // host validates; never index out of the table
+    long t = 0;
+    if (pe != nullptr) {
+      // quirk Q1 (model.py:136-137): expand(L,B,E).reshape(B,L,E) => row r receives pe[y[r % B]]
+      t = tvec ? tvec[row % B] : (long)(state->t_start - state->step);
+      if (t < 0) t = 0;
+      if (t >= n_timesteps) t = n_timesteps - 1;
+    }
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if (j < E) acc = fmaf(up_w[c * E + j], e[j], acc);
-    X[(long)row * D + c] = acc + up_b[c];
+      if (j < E) {
+        float e = emb[tok * E + j];               // wave-uniform addresses: broadcast loads
+        if (pe != nullptr) e = pe[t * E + j] + e;
+        acc = fmaf(w[j], e, acc);
+      }
+    if (c_on) X[(long)row * D + c] = acc + bias;
   }
 }
 
@@ -510,7 +517,8 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
                         const float* pe, int n_timesteps, const float* up_w, const float* up_b, float* X,
                         int rows, int B, int D, int E, int n_tokens, hipStream_t stream) {
   if (E > 16 || rows <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, stream, tokens, tvec, state, emb, pe, n_timesteps,
+  const dim3 grid((rows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK, (D + 255) / 256);
+  hipLaunchKernelGGL(embed_kernel, grid, dim3(256), 0, stream, tokens, tvec, state, emb, pe, n_timesteps,
                      up_w, up_b, X, rows, B, D, E, n_tokens);
   return hipGetLastError();
 }
