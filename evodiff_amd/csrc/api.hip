@@ -117,7 +117,7 @@ struct ed_model {
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   bool prune = true;           // ED_OPT_PRUNE
-  int min_tuned_tiles = 70;    // ED_OPT_MIN_TUNED_TILES
+  int min_tuned_tiles = 130;   // ED_OPT_MIN_TUNED_TILES (tiles of the height the tuned kernel would use)
   std::vector<LayerPlan> plan; // per layer, for the current (B, L)
   int plan_s_final = 1;        // stride of the position set the last block produces
   long conv_pitch = 0, conv_row0 = 0;  // layout of Cpad: [B][conv_pitch][d_hidden], position 0 at row conv_row0
@@ -226,11 +226,12 @@ struct Probe {
                                       __FILE__, __LINE__);                                               \
   } while (0)
 
-// The tuned kernel works on 256-row x 256/320-column tiles, one per CU at a time: a problem with few such tiles
-// leaves most of the chip idle, and the small-tile generic kernel is the faster one.
+// The tuned kernels work on 256-row (128-row for mid-size problems) x 256/320-column tiles, one per CU at a time: a
+// problem with few such tiles leaves most of the chip idle, and the small-tile generic kernel is the faster one.
 bool use_tuned_gemm(const ed_model* m, const GemmProblem& p) {
   if (!p.a_bf16 || !gemm_bf16_supported(p)) return false;
-  const long tiles = (long)p.B * ((p.L + 255) / 256) * (p.N % 320 == 0 ? p.N / 320 : p.N / 256);
+  const int rows = gemm_bf16_tile_rows(p);
+  const long tiles = (long)p.B * ((p.L + rows - 1) / rows) * (p.N % 320 == 0 ? p.N / 320 : p.N / 256);
   return tiles >= m->min_tuned_tiles;
 }
 
@@ -280,6 +281,10 @@ int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, 
   LAUNCH_TRY(pr.end(ED_K_LNACT, 0.0, (double)rows * C * ((in_bf16 ? 2.0 : 4.0) + (out_bf16 ? 2.0 : 4.0))));
   return ED_OK;
 }
+
+// Largest window problem (in 256-row tiles) an incremental leading layer may have: beyond it recomputing the
+// window on the small-tile kernel is no cheaper than the whole layer on the tuned one (measured at B = 64).
+constexpr long INC_MAX_TILES = 70;
 
 int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   const ed_config& c = m->cfg;
@@ -347,7 +352,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
       r += (c.kernel_size / 2) * m->layers[k].dilation;
       const long M = 2L * r + 1;
       const long tiles = ((long)B * M + 255) / 256 * ((c.d_hidden + 319) / 320);
-      if (M * 2 > L || tiles >= m->min_tuned_tiles || m->plan[k].s_out > 1 || m->plan[k + 1].s_out > 1) break;
+      if (M * 2 > L || tiles >= INC_MAX_TILES || m->plan[k].s_out > 1 || m->plan[k + 1].s_out > 1) break;
       m->inc_r[k + 1] = r;
       m->n_inc = k + 1;
     }

@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-constexpr int BM = 256, BK = 64, ROW_B = BK * 2;
+constexpr int SEQ_ROWS = 256, BK = 64, ROW_B = BK * 2;
 constexpr int WIN_ROWS = 320, WIN_BYTES = WIN_ROWS * ROW_B;
 constexpr int NTAPS = 5;
 
@@ -48,20 +48,27 @@ struct WindowPlan {
   int win_groups;  // 8-row copy groups of the window
   int wofs;        // window rows in front of the tile's first position (2d; whole-sequence form: 32 or 0)
   int tap_lo, tap_hi;  // taps in the K loop (whole-sequence form drops taps no position of the tile can reach)
-  int clip;        // whole-sequence form: a wave skips the taps that move all of its 64 rows outside [0, 256)
-  int na;          // window groups each wave copies per step (1 or 2)
+  int clip;        // whole-sequence form: a wave skips the taps that move all of its 64 rows outside [0, 256);
+                   // the window then starts at position -wofs of the SEQUENCE, whichever tile the workgroup owns
+  int na;          // window groups each wave copies per step (1 .. 3)
 };
 
 // STAMP: diagnostic build that also records the K loop's duration (GemmProblem::stamps).
-template <int NT, bool OUT_BF16, bool STAMP = false>
-__global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total, WindowPlan wp) {
+// WM: waves along M, as in gemm_bf16.hip: 4 = 256-row tile, 2 = 128-row tile (4 waves) for launches that would
+// leave half of the CUs without a 256-row tile.
+template <int NT, bool OUT_BF16, bool STAMP = false, int WM = 4>
+__global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total,
+                                                               WindowPlan wp) {
+  constexpr int BM = WM * 64;      // tile rows
+  constexpr int NW = 2 * WM;       // waves
   constexpr int BN = NT * 64;
   constexpr int W_BYTES = BN * ROW_B;
-  constexpr int NGB = BN / 64;     // 8-row copy groups of the weight tile per wave and step
+  constexpr int NGB = BN / (8 * NW);  // 8-row copy groups of the weight tile per wave and step
   constexpr int NJ = 2 * NT;       // 16-column output tiles per wave
   constexpr int NGRP = 2 * NJ;     // (32-channel k-slice, column tile) groups of 4 MFMAs per step
   constexpr int RING = 4;          // weight fragments in flight
   static_assert(NGRP % RING == 0, "the fragment ring must line up across steps");
+  static_assert(NGB + 3 < NGRP, "copy slots of a step");
   __shared__ __attribute__((aligned(1024))) char lds[2 * WIN_BYTES + 2 * W_BYTES];
   char* const lds_w = lds + 2 * WIN_BYTES;
 
@@ -90,8 +97,9 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   const unsigned lane_off0 = lane_row + (((lane & 7) ^ (lane >> 4)) << 4);
   const unsigned lane_off1 = lane_row + (((lane & 7) ^ (4 + (lane >> 4))) << 4);
   const unsigned grp_bytes = (unsigned)(8 * row_bytes);
-  // window row 0 = position l0 - wofs of sequence b
-  const char* a_next = (const char*)g.A + ((long)b * g.a_seq_pitch + g.a_row0 + l0 - wp.wofs) * row_bytes;
+  // window row 0 = position lw - wofs of sequence b
+  const int lw = wp.clip ? 0 : l0, lt = l0 - lw;  // window origin; tile's first position relative to it
+  const char* a_next = (const char*)g.A + ((long)b * g.a_seq_pitch + g.a_row0 + lw - wp.wofs) * row_bytes;
   const char* w_dma = (const char*)g.W + ((long)wp.tap_lo * g.N + n0) * row_bytes;  // first tap, slice 0, first channel
   const unsigned w_lane_extra = (unsigned)((lane >> 5) * 4 * row_bytes);  // permuted rows: group row k reads channel + 4*(k >> 2)
   const long w_tap_step = (long)g.N * row_bytes;
@@ -127,13 +135,13 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   // ---- fragment addressing: 16 rows x 32 channels per fragment, lane = (row fr, 8-channel chunk fq)
   const int b_rd = (wc * (BN / 2) + fr) * ROW_B;
   const int b_x = (fq ^ ((fr >> 1) & 7)) << 4;
-  const int a_row = wr * 64 + fr + wp.wofs - 2 * d;  // window row of this lane's first activation fragment at tap 0
+  const int a_row = lt + wr * 64 + fr + wp.wofs - 2 * d;  // window row of this lane's first activation fragment at tap 0
   bf16x8 fact[2][4], fw[RING];
 
   // prologue: window of slice 0 and weights of step 0
   {
 #pragma unroll
-    for (int k = 0; k < WIN_ROWS / 64; ++k) copy_window_group(k * 8 + wid, lds);
+    for (int k = 0; k < WIN_ROWS / (8 * NW); ++k) copy_window_group(k * NW + wid, lds);
 #pragma unroll
     for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, lds_w);
     w_dma += ntaps > 1 ? w_tap_step : w_wrap_step;
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
   // fragment three groups ahead, a read of the second k-slice's activation fragments, or one of the step's copies.
   auto step = [&](int tap, int j, const char* win, char* win_next, const char* wst, char* wst_next) {
     // whole-sequence form: rows [64 wr + (tap-2) d, +64) of this wave; all of them outside [0, 256) = all zeros
-    const int first = wr * 64 + (tap - 2) * d;
-    const bool active = !wp.clip || (first + 64 > 0 && first < BM);
+    const int first = lt + wr * 64 + (tap - 2) * d;
+    const bool active = !wp.clip || (first + 64 > 0 && first < SEQ_ROWS);
     if (active) {
       const int shift = tap * d;  // window rows between tap 0 and this tap
       const char* a_base = win + (a_row + shift) * ROW_B;
@@ -175,8 +183,9 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
             if (grp >= 1 && grp <= 4) read_act(1, grp - 1);
           } else if (ip == 2) {
             if (grp >= 1 && grp <= NGB) copy_weight_group(grp - 1, wst_next);
-            else if (grp == NGB + 1) copy_window_group((j * wp.na) * 8 + wid, win_next);
-            else if (grp == NGB + 2 && wp.na > 1) copy_window_group((j * wp.na + 1) * 8 + wid, win_next);
+            else if (grp == NGB + 1) copy_window_group((j * wp.na) * NW + wid, win_next);
+            else if (grp == NGB + 2 && wp.na > 1) copy_window_group((j * wp.na + 1) * NW + wid, win_next);
+            else if (grp == NGB + 3 && wp.na > 2) copy_window_group((j * wp.na + 2) * NW + wid, win_next);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -185,8 +194,9 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
       // nothing to multiply in this step: only this wave's share of the copies
 #pragma unroll
       for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, wst_next);
-      copy_window_group((j * wp.na) * 8 + wid, win_next);
-      if (wp.na > 1) copy_window_group((j * wp.na + 1) * 8 + wid, win_next);
+      copy_window_group((j * wp.na) * NW + wid, win_next);
+      if (wp.na > 1) copy_window_group((j * wp.na + 1) * NW + wid, win_next);
+      if (wp.na > 2) copy_window_group((j * wp.na + 2) * NW + wid, win_next);
     }
   };
 
@@ -251,55 +261,67 @@ __global__ __launch_bounds__(512) void conv_window_kernel(GemmProblem g, int til
 
 // Shape contract (on top of gemm_bf16_supported): five taps, no residual, and either
 //  - the window of 256 + 4*dilation rows fits the 320-row LDS window (dilation <= 16), or
-//  - whole-sequence form: L <= 256 (one tile per sequence, so every row outside the tile is zero padding) and
-//    dilation 32 or a multiple of 64 - then each 64-row wave slice of a tap is either entirely padding (skipped)
-//    or inside the window [-wofs, 256 + wofs).
+//  - whole-sequence form: L <= 256 (every row outside [0, 256) is zero padding) and dilation 32 or a multiple of
+//    64 - then each 64-row wave slice of a tap is either entirely padding (skipped) or inside the window
+//    [-wofs, 256 + wofs).
 // Memory contract: A rows [a_row0 - 2*dilation, a_row0 + ceil(L/256)*256 + 2*dilation + 8) of every sequence are
 // readable, and rows outside [0, L) hold zeros.
-static bool window_plan(const GemmProblem& p, WindowPlan* wp) {
+static bool window_plan(const GemmProblem& p, int wm, WindowPlan* wp) {
   if (!gemm_bf16_supported(p) || p.ntaps != NTAPS || p.resid) return false;
-  const int d = p.dilation;
-  if (BM + 4 * d <= WIN_ROWS) {
-    *wp = WindowPlan{(BM + 4 * d + 7) / 8, 2 * d, 0, NTAPS - 1, 0, 1};
-    return true;
+  const int d = p.dilation, bm = wm * 64, nw = 2 * wm;
+  // (the same dilations whatever the tile height: the window forms add up slice-major, the per-tap form tap-major,
+  // and a launch's results must not depend on which tile height its size selects)
+  if (SEQ_ROWS + 4 * d <= WIN_ROWS) {
+    const int groups = (bm + 4 * d + 7) / 8;
+    *wp = WindowPlan{groups, 2 * d, 0, NTAPS - 1, 0, (groups + nw * NTAPS - 1) / (nw * NTAPS)};
+    return wp->na <= 3;
   }
-  if (p.L <= BM && (d == 32 || d % 64 == 0)) {
+  if (p.L <= SEQ_ROWS && (d == 32 || d % 64 == 0)) {
     const int wofs = d == 32 ? 32 : 0;
     int lo = 0, hi = NTAPS - 1;
-    while ((2 - lo) * d >= BM) ++lo;
-    while ((hi - 2) * d >= BM) --hi;
-    const int groups = (BM + 2 * wofs) / 8, nt = hi - lo + 1;
-    *wp = WindowPlan{groups, wofs, lo, hi, 1, (groups + 8 * nt - 1) / (8 * nt)};
-    return wp->na <= 2;
+    while ((2 - lo) * d >= SEQ_ROWS) ++lo;
+    while ((hi - 2) * d >= SEQ_ROWS) --hi;
+    const int groups = (SEQ_ROWS + 2 * wofs) / 8, nt = hi - lo + 1;
+    *wp = WindowPlan{groups, wofs, lo, hi, 1, (groups + nw * nt - 1) / (nw * nt)};
+    return wp->na <= (wm == 4 ? 2 : 3);
   }
   return false;
 }
 
+// 128-row tiles when 256-row tiles would cover at most half of the CUs (same rule as gemm_bf16.hip)
+static int window_wm(const GemmProblem& p, WindowPlan* wp) {
+  if (gemm_bf16_tile_rows(p) == 128 && window_plan(p, 2, wp)) return 2;
+  return window_plan(p, 4, wp) ? 4 : 0;
+}
+
 bool conv_window_supported(const GemmProblem& p) {
   WindowPlan wp;
-  return window_plan(p, &wp);
+  return window_wm(p, &wp) != 0;
 }
 
 hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream) {
   WindowPlan wp;
-  if (!window_plan(p, &wp)) return hipErrorInvalidValue;
-  const dim3 block(512);
-#define ED_GO(NTV, OB)                                                                                   \
-  {                                                                                                      \
-    const int tiles_n = p.N / (NTV * 64);                                                                \
-    const int tiles_total = p.B * ((p.L + BM - 1) / BM) * tiles_n;                                       \
-    if (p.ablate == 7 && p.stamps)                                                                       \
-      hipLaunchKernelGGL((conv_window_kernel<NTV, OB, true>), dim3(tiles_total), block, 0, stream, p,    \
-                         tiles_n, tiles_total, wp);                                              \
-    else                                                                                                 \
-      hipLaunchKernelGGL((conv_window_kernel<NTV, OB>), dim3(tiles_total), block, 0, stream, p, tiles_n, \
-                         tiles_total, wp);                                                       \
+  const int wm = window_wm(p, &wp);
+  if (!wm) return hipErrorInvalidValue;
+#define ED_GO(NTV, OB, WMV)                                                                               \
+  {                                                                                                       \
+    const int tiles_n = p.N / (NTV * 64);                                                                 \
+    const int tiles_total = p.B * ((p.L + WMV * 64 - 1) / (WMV * 64)) * tiles_n;                          \
+    if (p.ablate == 7 && p.stamps)                                                                        \
+      hipLaunchKernelGGL((conv_window_kernel<NTV, OB, true, WMV>), dim3(tiles_total), dim3(WMV * 128), 0, \
+                         stream, p, tiles_n, tiles_total, wp);                                            \
+    else                                                                                                  \
+      hipLaunchKernelGGL((conv_window_kernel<NTV, OB, false, WMV>), dim3(tiles_total), dim3(WMV * 128), 0, \
+                         stream, p, tiles_n, tiles_total, wp);                                            \
   }
+#define ED_GO2(NTV, OB) \
+  if (wm == 2) ED_GO(NTV, OB, 2) else ED_GO(NTV, OB, 4)
   if (p.N % 320 == 0) {
-    if (p.out_bf16) ED_GO(5, true) else ED_GO(5, false)
+    if (p.out_bf16) ED_GO2(5, true) else ED_GO2(5, false)
   } else {
-    if (p.out_bf16) ED_GO(4, true) else ED_GO(4, false)
+    if (p.out_bf16) ED_GO2(4, true) else ED_GO2(4, false)
   }
+#undef ED_GO2
 #undef ED_GO
   return hipGetLastError();
 }

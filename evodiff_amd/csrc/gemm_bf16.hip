@@ -45,11 +45,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // ABLATE (diagnostic builds): 1 = no MFMAs, 2 = no DMA copies (results invalid); 3 = in-kernel clock stamps.
 // RT > 0 (1x1 + residual only): the K loop has exactly RT steps and is fully unrolled, and the residual tile is
 // streamed in DURING the loop (see below) instead of before it.
-template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
+// WM: waves along M (2 along N always).  4 = the 256-row tile; 2 = a 128-row tile with 4 waves (one per SIMD) for
+// problems that would fill less than half the chip with 256-row tiles: every wave keeps its 64 x BN/2 sub-tile and
+// copies twice as many weight groups.
+template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0, int WM = 4>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
+  constexpr int BM = WM * 64;       // (shadows the file-scope 256)
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
-  constexpr int NGB = BN / 64;      // 8-row DMA groups of the W tile per wave (A: 4 per wave)
+  constexpr int NGB = BN / (16 * WM);  // 8-row DMA groups of the W tile per wave (A: 4 per wave)
   constexpr int N_DMA = 4 + NGB;    // copies per wave per step
   constexpr int NJ = 2 * NT;        // 16-column output tiles per wave
   constexpr int NGRP = 2 * NJ;      // (32-channel k-slice, column tile) groups of 4 MFMAs per step
@@ -295,34 +299,41 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmProblem g, int tiles
   }
 }
 
-template <int NT, bool CONV>
+template <int NT, bool CONV, int WM>
 hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
+  constexpr int BMT = WM * 64;
   const int tiles_n = p.N / (NT * 64);
-  const int tiles_total = p.B * ((p.L + BM - 1) / BM) * tiles_n;
-  const dim3 grid(tiles_total), block(512);
+  const int tiles_total = p.B * ((p.L + BMT - 1) / BMT) * tiles_n;
+  const dim3 grid(tiles_total), block(WM * 128);
 #define ED_GO(OB, RS, AB) \
-  hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB>), grid, block, 0, stream, p, tiles_n, tiles_total)
+  hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB, 0, WM>), grid, block, 0, stream, p, tiles_n, tiles_total)
   if (p.ablate == 1) ED_GO(false, false, 1);
   else if (p.ablate == 2) ED_GO(false, false, 2);
   else if (p.ablate == 7 && p.stamps) {
     if (p.resid && p.K == 20 * BK && p.resid_mul == 1 && !CONV)
-      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 3, 20>), grid, block, 0, stream, p, tiles_n, tiles_total);
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 3, 20, WM>), grid, block, 0, stream, p, tiles_n, tiles_total);
     else if (p.resid) ED_GO(false, true, 3);
     else ED_GO(true, false, 3);
   }
   else if (p.resid) {
     // hidden-residual form: 1x1, every tile full, K loop of a known length
-    const bool whole = !CONV && ((long)p.B * p.L) % BM == 0 && (p.B == 1 || p.L % BM == 0) && p.resid_mul == 1;
+    const bool whole = !CONV && ((long)p.B * p.L) % BMT == 0 && (p.B == 1 || p.L % BMT == 0) && p.resid_mul == 1;
     if (whole && p.K == 20 * BK)
-      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 20>), grid, block, 0, stream, p, tiles_n, tiles_total);
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 20, WM>), grid, block, 0, stream, p, tiles_n, tiles_total);
     else if (whole && NT == 4 && p.K == 8 * BK)
-      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 8>), grid, block, 0, stream, p, tiles_n, tiles_total);
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 8, WM>), grid, block, 0, stream, p, tiles_n, tiles_total);
     else ED_GO(false, true, 0);
   }
   else if (p.out_bf16) ED_GO(true, false, 0);
   else ED_GO(false, false, 0);
 #undef ED_GO
   return hipGetLastError();
+}
+
+template <int NT, bool CONV>
+hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
+  if (gemm_bf16_tile_rows(p) == 128) return launch_nt<NT, CONV, 2>(p, stream);
+  return launch_nt<NT, CONV, 4>(p, stream);
 }
 
 }  // namespace

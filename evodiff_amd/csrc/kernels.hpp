@@ -83,6 +83,14 @@ hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream);
 hipError_t launch_reduce_partials(const GemmProblem& p, hipStream_t stream);
 // Tuned bf16 kernel (see gemm_bf16.hip for its shape requirements); false = shape not supported.
 bool gemm_bf16_supported(const GemmProblem& p);
+// Tile height the tuned kernels use for a problem: 256 rows, or 128 when 256-row tiles would cover at most half of
+// the 256 CUs (ablate != 0, the diagnostic forms, always use 256).
+inline long gemm_bf16_full_tiles(const GemmProblem& p) {
+  return (long)p.B * ((p.L + 255) / 256) * (p.N % 320 == 0 ? p.N / 320 : p.N / 256);
+}
+inline int gemm_bf16_tile_rows(const GemmProblem& p) {
+  return p.ablate == 0 && gemm_bf16_full_tiles(p) <= 128 ? 128 : 256;
+}
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream);
 // Window-in-LDS form of the dilated convolution (conv_window.hip): five taps, dilation <= 16; launch_gemm_bf16
 // picks it by itself when the shape allows (GemmProblem::ablate == 3 keeps the per-tap form, for comparisons).

@@ -127,8 +127,9 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
  *   ED_OPT_INCREMENTAL (default 1): between two steps of ed_oadm_sample one token per sequence changes, so
  *     the leading blocks (dilations 1, 2, 4 at config 2) keep their outputs from the previous step and recompute
  *     only the rows within their receptive field of the changed position.  0 = recompute every row.
- *   ED_OPT_MIN_TUNED_TILES (default 70): GEMMs with fewer 256-row tiles than this use the small-tile
- *     kernel instead of the tuned one (0 = tuned kernel whenever the shape allows).
+ *   ED_OPT_MIN_TUNED_TILES (default 130): GEMMs with fewer tiles than this (tiles of the height the tuned kernel
+ *     would pick: 128 rows up to 128 tiles of 256 rows, 256 rows above) use the small-tile kernel instead of the
+ *     tuned one (0 = tuned kernel whenever the shape allows).
  *   ED_OPT_SPLIT_TARGET (default 512): bf16 GEMMs on the small-tile kernel with fewer workgroups than this
  *     have their K loop cut across workgroups (partial sums added in a fixed order); 0 = never. */
 enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1, ED_OPT_SPLIT_TARGET = 2, ED_OPT_INCREMENTAL = 3 };

@@ -341,7 +341,7 @@ def test_full_size_batch_invariance_640m(dev):
     assert torch.equal(pb[:, 62:64], ps)
     assert int((big != tok.mask_id).sum()) == B * n
     # default kernel choice (small problems on the small-tile kernel): same softmax rows within bf16 noise
-    m.set_option("min_tuned_tiles", 70)
+    m.set_option("min_tuned_tiles", 130)
     m.set_option("prune", 1)
     big2 = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
     pb2 = m.oadm_sample(big2, order[:1], uni[:1], R.OADM_DRAW, return_probs=True)
@@ -429,7 +429,7 @@ def test_38m_config5_full_size_batch_invariance(dev):
     assert torch.equal(pb[:, 1020:1024], ps)
     assert int((big != tok.mask_id).sum()) == B * n
     # the small batch against the oracle (same seeded default init), first step, default execution options
-    m.set_option("min_tuned_tiles", 70)
+    m.set_option("min_tuned_tiles", 130)
     m.set_option("prune", 1)
     torch.manual_seed(0)
     oracle = R.build_model(R.MODEL_CONFIGS["38M"], None, None)

@@ -6,8 +6,8 @@ m, _, tok, _ = OA_DM_640M(random_init=True)
 m.precision = "bf16"
 dev = torch.device("cuda", 0)
 L, n = 256, 24
-for B in (16, 32, 64):
-    for tiles in (40, 70, 130, 260):
+for B in (16, 24, 32, 48, 64):
+    for tiles in (70, 130, 140):
         m.set_option("min_tuned_tiles", tiles)
         order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
         uni = torch.rand((n, B), device=dev)
