@@ -11,7 +11,7 @@ before the timed region.  Rank 0 prints ONE JSON line.
 
 roofline: the dominant kernel is the windowed dilated convolution (conv_window_kernel: the convolution of every
 block at L <= 256, 46 % of a step's time).  Its launches are timed live with HIP-event pairs on the launch stream on
-every 32nd diffusion step inside the timed region; achieved = algorithmic FLOPs of those launches (in-range taps
+every 64th diffusion step inside the timed region; achieved = algorithmic FLOPs of those launches (in-range taps
 only) / their summed duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.  traffic = memory-side
 bytes of one such launch (dilation 1) from the committed PMC passes (profiles/, tools/pmc_traffic.sh), for the
 default config only.  cpu_baseline: the CPU oracle (a port of the reference's PyTorch path) timed on this host for
@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--probe-every", type=int, default=32)
+    ap.add_argument("--probe-every", type=int, default=64)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
