@@ -828,6 +828,41 @@ int ed_forward(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_
   return ed_forward_collect(m, tokens_dev, timesteps_dev, B, L, logits_dev, nullptr, precision, stream);
 }
 
+int ed_score_nll(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, const int64_t* targets_dev,
+                 const uint8_t* select_dev, int B, int L, int n_classes, float* nll_dev, int precision, void* stream) {
+  int rc = check_shape(m, B, L, precision);
+  if (rc) return rc;
+  if (!tokens_dev || !targets_dev || !nll_dev) return fail(ED_EINVAL, "null tokens/targets/nll pointer");
+  if (m->cfg.timesteps > 0 && !timesteps_dev) return fail(ED_EINVAL, "timesteps_dev is required for a model with timestep encoding");
+  if (n_classes < 1 || n_classes > m->cfg.n_tokens) return fail(ED_EINVAL, "n_classes must be in [1, n_tokens]");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(m->device));
+  {  // the target indexes the logits: validate it on the host before any kernel uses it
+    const size_t n = (size_t)B * L;
+    std::vector<int64_t> tg(n);
+    std::vector<uint8_t> sel(select_dev ? n : 0);
+    HIP_TRY(hipMemcpyAsync(tg.data(), targets_dev, n * 8, hipMemcpyDeviceToHost, s));
+    if (select_dev) HIP_TRY(hipMemcpyAsync(sel.data(), select_dev, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; ++i)
+      if ((!select_dev || sel[i]) && (tg[i] < 0 || tg[i] >= n_classes))
+        return fail(ED_EINVAL, "targets[%zu] = %lld is outside [0, n_classes=%d)", i, (long long)tg[i], n_classes);
+  }
+  if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
+  m->probing_now = m->probe_every > 0;
+  rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, STEP_PLAIN, s);
+  if (!rc) rc = run_blocks(m, B, L, precision, nullptr, false, STEP_PLAIN, nullptr, s);
+  if (!rc) {
+    Probe pr(m, s);
+    LAUNCH_TRY(pr.begin());
+    LAUNCH_TRY(launch_final_nll(m->X.as<float>(), m->last_g, m->last_b, m->dec_w, m->dec_b, targets_dev, select_dev,
+                                nll_dev, B * L, m->cfg.d_model, n_classes, s));
+    LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * L * n_classes * m->cfg.d_model, (double)B * L * m->cfg.d_model * 4.0));
+  }
+  m->probing_now = false;
+  return rc;
+}
+
 int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, const float* uniforms_dev, int B,
                    int L, int n_steps, int n_draw, float* probs_dev, int precision, int use_graph, void* stream) {
   int rc = check_shape(m, B, L, precision);

@@ -425,6 +425,34 @@ __device__ __forceinline__ float lane_softmax(float logit, int lane, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Scoring tail: analysis/sequence_perp.py:127-154.  last_norm + decoder + cross entropy of the first n_classes logits
+// against the target token, one wave per (sequence, position); nll = logsumexp(x) - x[target] computed as torch's
+// log_softmax does (x - max - log(sum exp(x - max))).  Rows with select[row] == 0 are skipped and score 0.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void final_nll_kernel(const float* __restrict__ X, const float* gamma,
+                                                        const float* beta, const float* dec_w, const float* dec_b,
+                                                        const int64_t* __restrict__ targets,
+                                                        const uint8_t* __restrict__ select, float* __restrict__ nll,
+                                                        int rows, int D, int n_classes) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  if (select != nullptr && select[row] == 0) {  // wave-uniform
+    if (lane == 0) nll[row] = 0.f;
+    return;
+  }
+  const float logit = row_logits<NCH>(X, row, D, lane, gamma, beta, dec_w, dec_b, n_classes);
+  const float x = lane < n_classes ? logit : -INFINITY;
+  const float m = wave_max(x);
+  const float ssum = wave_sum(lane < n_classes ? expf(x - m) : 0.f);
+  long t = targets[row];
+  if (t < 0 || t >= n_classes) t = 0;           // host validates; keep the lane index in range regardless
+  const float xt = __shfl(logit, (int)t);
+  if (lane == 0) nll[row] = -((xt - m) - logf(ssum));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // OA-DM tail: generate.py:198-211.  One wave per sequence; only row order[step] is decoded.
 // ---------------------------------------------------------------------------------------------------
 template <int NCH>
@@ -614,6 +642,19 @@ hipError_t launch_final_logits(const float* X, const float* gamma, const float* 
   const dim3 grid((rows + 3) / 4), block(256);
 #define ED_CALL(N) \
   hipLaunchKernelGGL((final_logits_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, logits, rows, D, n_tokens)
+  ED_NCH_DISPATCH(D, ED_CALL);
+#undef ED_CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_final_nll(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                            const float* dec_b, const int64_t* targets, const uint8_t* select, float* nll, int rows,
+                            int D, int n_classes, hipStream_t stream) {
+  if (D % 4 != 0 || n_classes > 64 || n_classes < 1 || rows <= 0) return hipErrorInvalidValue;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define ED_CALL(N)                                                                                                \
+  hipLaunchKernelGGL((final_nll_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, targets, select, \
+                     nll, rows, D, n_classes)
   ED_NCH_DISPATCH(D, ED_CALL);
 #undef ED_CALL
   return hipGetLastError();

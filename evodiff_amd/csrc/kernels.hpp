@@ -128,6 +128,9 @@ hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16,
                          const float* beta, int rows, int C, const LnRowMap& map, int act, hipStream_t stream);
 
 // logits[r][k] = dec_b[k] + dec_w[k] . LayerNorm(X[r])  for all rows (ByteNetLMTime.forward tail).
+hipError_t launch_final_nll(const float* X, const float* gamma, const float* beta, const float* dec_w,
+                            const float* dec_b, const int64_t* targets, const uint8_t* select, float* nll, int rows,
+                            int D, int n_classes, hipStream_t stream);
 hipError_t launch_final_logits(const float* X, const float* gamma, const float* beta, const float* dec_w,
                                const float* dec_b, float* logits, int rows, int D, int n_tokens,
                                hipStream_t stream);

@@ -73,6 +73,31 @@ def generate_oaardm(model, tokenizer, seq_len, penalty=None, batch_size=3, devic
     return sample, untokenized
 
 
+def generate_oaardm_order_opt(model, tokenizer, seq_len, penalty=None, batch_size=20, device='cuda', *, uniforms=None):
+    """``generate.py:151-177``: the next position is the most confident masked one (argmax of the probabilities over
+    the whole flattened batch, :169-170), its token is drawn from batch element 0's distribution (:172) and written
+    into every sequence (:174) - the batch stays identical, as in the reference.  Needs every position's logits, so
+    each step is one ``ed_forward``; the selection runs on the device."""
+    n_draw = len(tokenizer.all_aas) - 6
+    mask = tokenizer.mask_id
+    sample = torch.full((batch_size, seq_len), mask, dtype=torch.long, device=device)
+    timestep = torch.zeros(batch_size, dtype=torch.long, device=device)
+    if uniforms is None:
+        uniforms = torch.rand(seq_len, dtype=torch.float32, device=device)
+    uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device)
+    with torch.no_grad():
+        for s in range(seq_len):
+            p = torch.softmax(model(sample, timestep)[:, :, :n_draw], dim=-1)
+            p[(sample != mask).unsqueeze(-1).expand(p.shape)] = 0        # ignore positions already sampled
+            # argmax over the FLATTENED batch, as there; the rows are copies of each other, and only the FIRST maximum
+            # (CPU torch.argmax's choice) indexes row 0 - a device argmax does not promise which tie it returns
+            flat = p.view(-1)
+            idx = torch.nonzero(flat == flat.max())[0]
+            pos = torch.div(idx, p.shape[-1], rounding_mode='trunc')
+            sample[:, pos] = _inverse_cdf(p[0, pos], uniforms[s].reshape(1))
+    return sample, _strings(tokenizer, sample)
+
+
 def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, batch_size=3, device='cuda', *, uniforms=None,
                   start=None):
     """Start from uniformly random tokens and run the reverse chain t = timesteps-1 ... 1."""

@@ -212,6 +212,35 @@ class ByteNetLMTime(nn.Module):
             _lib.check(lib.ed_forward(handle, x.data_ptr(), y.data_ptr(), B, L, logits.data_ptr(), self._prec(), stream))
         return logits
 
+    def score_nll(self, x, y, targets, select=None, n_classes=None):
+        """Forward + per-position cross entropy against ``targets`` (analysis/sequence_perp.py:125-154) on the GPU:
+        (B, L) fp32, zero where ``select`` (B, L) is false.  The logits are never materialised."""
+        if not x.is_cuda:
+            raise _lib.EvoDiffHipError("evodiff_amd has no CPU path: move the inputs to the GPU")
+        handle = self.hip_handle(x.device)
+        lib = _lib.load()
+        B, L = x.shape
+        n_classes = self.hparams["n_tokens"] if n_classes is None else int(n_classes)
+        x = x.to(torch.long).contiguous()
+        if int(x.min()) < 0 or int(x.max()) >= self.hparams["n_tokens"]:
+            raise IndexError("token id out of range")
+        y = y.to(device=x.device, dtype=torch.long).contiguous()
+        if self.hparams["timesteps"] > 0 and (y.numel() != B or int(y.min()) < 0 or int(y.max()) >= self.hparams["timesteps"]):
+            raise IndexError("y must hold one timestep in [0, timesteps) per sequence")
+        targets = targets.to(device=x.device, dtype=torch.long).contiguous()
+        if targets.shape != x.shape:
+            raise ValueError("targets must have the shape of x")
+        sel = None
+        if select is not None:
+            sel = select.to(device=x.device).reshape(B, L).ne(0).to(torch.uint8).contiguous()
+        nll = torch.empty((B, L), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ed_score_nll(handle, x.data_ptr(), y.data_ptr(), targets.data_ptr(),
+                                        sel.data_ptr() if sel is not None else None, B, L, n_classes, nll.data_ptr(),
+                                        self._prec(), stream))
+        return nll
+
     # ------------------------------------------------------------------ fused sampling loops (C ABI)
     def oadm_sample(self, sample, order, uniforms, n_draw, return_probs=False):
         """Loop of generate_oaardm (generate.py:193-211) on the GPU; ``sample`` (B, L) is updated in place."""

@@ -96,6 +96,15 @@ int ed_forward(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_
 int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
                        float* logits_dev, float* acts_dev, int precision, void* stream);
 
+/* Replaces: the model call and the loss of sum_nll_mask (analysis/sequence_perp.py:125-154): one forward, then per
+ * position the cross entropy of the first n_classes logits against targets[b][l] (torch CrossEntropyLoss as used
+ * by OAMaskedCrossEntropyLoss, evodiff/losses.py:57-61, and by the D3PM branch, sequence_perp.py:133-134); the
+ * logits never leave the GPU.  select_dev (B*L bytes, may be NULL = every position): positions with a zero byte
+ * are skipped and score 0 (the OA-DM mask).  nll_dev receives B*L fp32 values; the caller sums them.
+ * Targets of selected positions must be in [0, n_classes): ED_EINVAL otherwise. */
+int ed_score_nll(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, const int64_t* targets_dev,
+                 const uint8_t* select_dev, int B, int L, int n_classes, float* nll_dev, int precision, void* stream);
+
 /* Replaces: the loop of generate_oaardm (evodiff/generate.py:193-211, penalty=None).
  * tokens_dev int64 (B, L), in/out (the caller fills it with mask_id for unconditional sampling);
  * order_dev int32 (n_steps,) = positions to fill (np.random.shuffle'd arange in the reference);

@@ -406,6 +406,46 @@ def generate_d3pm_ref(model, Q, Q_bar, timesteps, start, uniforms, K=26, n_steps
     return sample
 
 
+@torch.no_grad()
+def generate_oaardm_order_opt_ref(model, seq_len, batch_size, uniforms, n_draw: int = OADM_DRAW, trace=None):
+    """generate.py:151-177: at every step the position is the argmax of the masked positions' probabilities over
+    the WHOLE flattened batch (:169-170), the token is drawn from batch element 0's distribution there (:172) and
+    written into every sequence (:174).  ``uniforms`` (seq_len,) replace torch.multinomial by the inverse CDF."""
+    sample = torch.full((batch_size, seq_len), MASK_ID, dtype=torch.long)
+    timestep = torch.zeros(batch_size, dtype=torch.long)
+    for s in range(seq_len):
+        p = torch.softmax(model(sample, timestep)[:, :, :n_draw], dim=-1)
+        p[(sample != MASK_ID).unsqueeze(-1).expand(p.shape)] = 0
+        idx = torch.argmax(p.view(1, -1), dim=-1)
+        pos = torch.div(idx, p.shape[-1], rounding_mode="trunc")
+        aas, margin = inverse_cdf(p[0, pos], uniforms[s].reshape(1))
+        sample[:, pos] = aas
+        if trace is not None:
+            top2 = torch.topk(p[0].reshape(-1), 2).values        # (the other batch rows are copies of row 0)
+            trace.append({"pos": int(pos), "tok": int(aas), "margin": float(margin), "gap": float(top2[0] - top2[1])})
+    return sample
+
+
+@torch.no_grad()
+def sum_nll_ref(model, scheme: str, src, timestep, tgt, mask=None):
+    """The model call and loss of sum_nll_mask (analysis/sequence_perp.py:125-155) for the ByteNet schemes.
+    'mask': OAMaskedCrossEntropyLoss(reweight=False) (losses.py:46-70): summed CE over the masked positions, all
+    logits; returns (fraction masked, nll sum, masked tokens).  'd3pm': CrossEntropyLoss(reduction='sum') over every
+    position (:133-137); returns (timestep, nll sum, length)."""
+    outputs = model(src, timestep)
+    if scheme == "d3pm":
+        nll = torch.nn.functional.cross_entropy(outputs.squeeze(0), tgt.squeeze(0), reduction="sum").item()
+        return timestep, nll, int(tgt.squeeze(0).numel())
+    if scheme != "mask":
+        raise ValueError(scheme)
+    m = mask.bool().unsqueeze(-1)
+    n_mask = int(m.sum())
+    p = torch.masked_select(outputs, m).view(n_mask, -1)
+    t = torch.masked_select(tgt, m.squeeze(-1))
+    nll = torch.nn.functional.cross_entropy(p, t, reduction="none").sum().to(torch.float64).item()
+    return n_mask / int(tgt.squeeze(0).numel()), nll, n_mask
+
+
 def f_eff_per_sequence(cfg: dict, L: int) -> float:
     """Algorithmic FLOPs of one forward of one length-L sequence, in-range taps only."""
     d_model = cfg["d_model"]

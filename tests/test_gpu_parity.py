@@ -499,3 +499,68 @@ def test_errors_are_raised_not_faults(dev):
         m.oadm_sample(sample, torch.tensor([8]), torch.zeros((1, 2), device=dev), R.OADM_DRAW)   # position out of range
     with pytest.raises((ValueError, _lib.EvoDiffHipError)):
         m.d3pm_sample(sample, torch.zeros(1), torch.zeros(1), torch.zeros(1), 26)               # no timesteps
+
+
+def test_order_opt_sampler_against_reference_trace(golden_dir, dev):
+    """generate_oaardm_order_opt (generate.py:151-177), fp32, against the trace the reference's own
+    source produced: the same positions are picked and the same tokens drawn wherever neither the argmax nor the
+    draw is a near tie."""
+    from evodiff_amd.generate import generate_oaardm_order_opt
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(golden_dir, "order_opt_trace.npz"))
+    oracle = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    L = len(g["uniforms"])
+    trace = []
+    R.generate_oaardm_order_opt_ref(oracle, L, 2, torch.from_numpy(g["uniforms"]), trace=trace)
+    assert min(t["gap"] for t in trace) > 1e-4 and min(t["margin"] for t in trace) > DRAW_MARGIN_FP32, \
+        "fixture has a near tie: regenerate it with another seed"
+    m = product_model(oracle, TINY_WIDE, precision="fp32")
+    sample, strings = generate_oaardm_order_opt(m, Tokenizer(), L, batch_size=2, device=dev,
+                                                uniforms=torch.from_numpy(g["uniforms"]))
+    assert np.array_equal(sample.cpu().numpy(), g["final"])
+    assert strings == [str(s) for s in g["strings"]]
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_scoring_against_reference_losses(golden_dir, dev, precision, tol):
+    """sum_nll_mask (analysis/sequence_perp.py:101-156) through ed_score_nll against the losses the
+    reference's own collaters + losses produced (fixture scoring.npz); tolerance relative to the summed NLL."""
+    from evodiff_amd.sequence_perp import sum_nll_mask
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    oracle = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    m = product_model(oracle, TINY_WIDE, precision=precision)
+    for i in range(3):
+        batch = tuple(torch.from_numpy(g[f"oa{i}_{k}"]) for k in ("src", "timestep", "tgt", "mask"))
+        frac, nll, tokens = sum_nll_mask(None, (m, None, Tokenizer(), "mask"), device=dev, collated=batch)
+        ref = float(g[f"oa{i}_nll"])
+        assert tokens == int(g[f"oa{i}_tokens"]) and abs(nll - ref) <= tol * abs(ref), (i, nll, ref)
+    oracle = R.build_model(TINY, 500, 13)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    m = product_model(oracle, TINY, timesteps=500, precision=precision)
+    for i in range(2):
+        batch = (torch.from_numpy(g[f"d3{i}_src"]), None, torch.from_numpy(g[f"d3{i}_timestep"]),
+                 torch.from_numpy(g[f"d3{i}_tgt"]))
+        t_out, nll, tokens = sum_nll_mask(None, (m, None, Tokenizer(sequences=True), "d3pm"), device=dev, collated=batch)
+        ref = float(g[f"d3{i}_nll"])
+        assert tokens == batch[0].shape[1] and int(t_out) == int(batch[2]) and abs(nll - ref) <= tol * abs(ref)
+    # per-position values against the oracle's log-softmax, and the argument checks of the entry point
+    src, tgt = torch.from_numpy(g["oab_src"]).to(dev), torch.from_numpy(g["oab_tgt"]).to(dev)
+    with torch.no_grad():
+        oracle = R.build_model(TINY_WIDE, None, 12)
+        ref = torch.nn.functional.cross_entropy(oracle(src.cpu(), torch.zeros(3, dtype=torch.long)).transpose(1, 2),
+                                                tgt.cpu(), reduction="none")
+    m = product_model(oracle, TINY_WIDE, precision="fp32")
+    got = m.score_nll(src, torch.zeros(3, dtype=torch.long), tgt)
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-4
+    sel = torch.from_numpy(g["oab_mask"]).to(dev)
+    got = m.score_nll(src, torch.zeros(3, dtype=torch.long), tgt, select=sel)
+    assert rel_err(got.cpu().numpy(), (ref * sel.cpu()).numpy()) < 1e-4 and float(got[sel == 0].abs().max()) == 0.0
+    from evodiff_amd._lib import EvoDiffHipError
+    with pytest.raises(EvoDiffHipError, match="targets"):
+        m.score_nll(src, torch.zeros(3, dtype=torch.long), tgt, n_classes=21)   # pad / mask ids are >= 21

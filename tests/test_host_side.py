@@ -45,8 +45,6 @@ def test_model_requires_the_gpu_path():
     assert scheme == "mask" and tokenizer.mask_id == 28 and tokenizer.K == 27
     with pytest.raises(_lib.EvoDiffHipError):
         model(torch.zeros((1, 4), dtype=torch.long), torch.zeros(1, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
-        collater(["ACD"])
     with pytest.raises(Exception, match="Could not load"):
         pretrained.OA_DM_38M()                       # no network, no $EVODIFF_CHECKPOINT_DIR
 
@@ -130,3 +128,80 @@ def test_get_intervals_of_motif_positions():
     from evodiff_amd.conditional_generation import get_intervals
     assert get_intervals([3, 4, 5, 9, 10, 20, 21]) == ([3, 9, 20], [5, 10, 21])
     assert get_intervals([4, 7], single_res_domain=True) == ([4, 7], [4, 7])
+
+
+def test_oa_mask_collater_masks_d_minus_t_plus_one_positions():
+    """evodiff/collaters.py:77-107: src = tgt with num_mask positions replaced by the mask id, timesteps = num_mask,
+    padding with pad_id / 0 to the longest sequence of the batch."""
+    from evodiff_amd.collaters import OAMaskCollater
+    from evodiff_amd.utils import Tokenizer
+    tok = Tokenizer()
+    np.random.seed(3)
+    seqs = [("ACDEFGHIKLMNPQRSTVWY",), ("MKV",), ("A",)]
+    src, timesteps, tgt, masks = OAMaskCollater(tok)(seqs)
+    assert src.shape == tgt.shape == masks.shape == (3, 20) and src.dtype == tgt.dtype == torch.long
+    for i, (s,) in enumerate(seqs):
+        D = len(s)
+        m = masks[i].bool()
+        assert int(m.sum()) == int(timesteps[i]) and 1 <= int(timesteps[i]) <= D and not m[D:].any()
+        assert (src[i, :D][m[:D]] == tok.mask_id).all() and (src[i, :D][~m[:D]] == tgt[i, :D][~m[:D]]).all()
+        assert tok.untokenize(tgt[i, :D]) == s
+        assert (src[i, D:] == tok.pad_id).all() and (tgt[i, D:] == tok.pad_id).all()
+    assert int(timesteps[2]) == 1                                    # a length-1 sequence is always fully masked
+
+
+def test_d3pm_collater_corrupts_with_the_cumulative_matrix():
+    """evodiff/collaters.py:133-171: x_t ~ Categorical(onehot(x_0) @ Q_bar[t]); q_x holds those probabilities."""
+    from evodiff_amd.collaters import D3PMCollater
+    from evodiff_amd.utils import Tokenizer
+    tok = Tokenizer(sequences=True)
+    Q_prod, Q_t = tok.q_random_schedule(timesteps=50)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    seqs = [("ACDEFGHIKLMNPQRSTVWY" * 3,), ("MKVL",)]
+    src, src_1h, timesteps, tgt, tgt_1h, Q, Q_bar, q_x = D3PMCollater(tok, 50, Q_t, Q_prod)(seqs)
+    assert src.shape == tgt.shape == (2, 60) and src_1h.shape == tgt_1h.shape == q_x.shape == (2, 60, tok.K)
+    assert Q is Q_t and Q_bar is Q_prod and ((1 <= timesteps) & (timesteps < 50)).all()
+    for i, (s,) in enumerate(seqs):
+        D, t = len(s), int(timesteps[i])
+        assert torch.allclose(q_x[i, :D], Q_prod[t][tgt[i, :D]].to(q_x.dtype), atol=1e-7)   # row x_0 of Q_bar[t]
+        assert (src_1h[i, :D].argmax(-1) == src[i, :D]).all() and int(src[i, :D].max()) < tok.K
+        assert (src[i, D:] == tok.pad_id).all()
+    # late timesteps of the uniform schedule forget x_0: a 60-residue sequence cannot come back unchanged
+    np.random.seed(0)
+    big_t = D3PMCollater(tok, 50, Q_t, Q_prod)
+    big_t.num_timesteps = 50
+    out = big_t([seqs[0]])
+    assert int(out[2][0]) >= 1
+
+
+def test_perplexity_helper():
+    from evodiff_amd.sequence_perp import perplexity
+    assert abs(perplexity([2.0, 4.0], [1, 2]) - np.exp(2.0)) < 1e-12
+
+
+def test_collaters_reproduce_the_reference_draws(golden_dir):
+    """Same np.random / torch seeds => the same corrupted batches as evodiff/collaters.py run by the reference's own
+    source (fixture scoring.npz, oracle/make_golden_next.py)."""
+    from evodiff_amd.collaters import D3PMCollater, OAMaskCollater
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    seqs = [str(s) for s in g["seqs"]]
+    tok = Tokenizer()
+    for i, seq in enumerate(seqs):
+        np.random.seed(40 + i)
+        src, timestep, tgt, mask = OAMaskCollater(tok)([(seq,)])
+        for name, got in (("src", src), ("timestep", timestep), ("tgt", tgt), ("mask", mask)):
+            assert np.array_equal(got.numpy(), g[f"oa{i}_{name}"]) and got.numpy().dtype == g[f"oa{i}_{name}"].dtype, name
+    np.random.seed(50)
+    src, timestep, tgt, mask = OAMaskCollater(tok)([(s,) for s in seqs])
+    for name, got in (("src", src), ("timestep", timestep), ("tgt", tgt), ("mask", mask)):
+        assert np.array_equal(got.numpy(), g[f"oab_{name}"]), name
+    tok_u = Tokenizer(sequences=True)
+    Q_bar, Q = tok_u.q_random_schedule(timesteps=500)
+    for i, seq in enumerate(seqs[:2]):
+        np.random.seed(60 + i)
+        torch.manual_seed(60 + i)
+        out = D3PMCollater(tok_u, 500, Q, Q_bar)([(seq,)])
+        assert np.array_equal(out[0].numpy(), g[f"d3{i}_src"]) and np.array_equal(out[2].numpy(), g[f"d3{i}_timestep"])
+        assert np.array_equal(out[3].numpy(), g[f"d3{i}_tgt"]) and np.allclose(out[7].numpy(), g[f"d3{i}_qx"], atol=1e-12)

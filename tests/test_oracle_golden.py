@@ -157,3 +157,39 @@ def test_f_eff_matches_survey():
     # 640M L=256 → 1147.5 MFLOP per token-forward; 38M L=100 → 63.98
     assert abs(R.f_eff_per_sequence(R.MODEL_CONFIGS["640M"], 256) / 256 / 1e6 - 1147.5) < 0.5
     assert abs(R.f_eff_per_sequence(R.MODEL_CONFIGS["38M"], 100) / 100 / 1e6 - 63.98) < 0.05
+
+
+def test_order_opt_sampler_matches_reference_trace(golden_dir):
+    """generate_oaardm_order_opt (generate.py:151-177) executed by the reference's own source vs the restatement."""
+    g = load(golden_dir, "order_opt_trace.npz")
+    m = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        m.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])               # (digest of the sharpened model)
+    L = len(g["uniforms"])
+    trace = []
+    sample = R.generate_oaardm_order_opt_ref(m, L, 2, torch.from_numpy(g["uniforms"]), trace=trace)
+    assert np.array_equal(sample.numpy(), g["final"])
+    assert [t["tok"] for t in trace] == g["tok"].tolist()
+    assert sorted(t["pos"] for t in trace) == list(range(L))         # every position exactly once
+    assert (sample[0] == sample[1]).all()                            # the batch stays identical (:174)
+
+
+def test_scoring_losses_match_reference(golden_dir):
+    """sum_nll_mask's model call + loss (analysis/sequence_perp.py:125-155) on the reference collaters' outputs."""
+    g = load(golden_dir, "scoring.npz")
+    m = R.build_model(TINY_WIDE, None, 12)
+    with torch.no_grad():
+        m.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    for i in range(3):
+        src, tgt, mask = (torch.from_numpy(g[f"oa{i}_{k}"]) for k in ("src", "tgt", "mask"))
+        frac, nll, tokens = R.sum_nll_ref(m, "mask", src, torch.zeros(1, dtype=torch.long), tgt, mask)
+        assert tokens == int(g[f"oa{i}_tokens"]) and abs(frac - tokens / src.shape[1]) < 1e-12
+        assert abs(nll - float(g[f"oa{i}_nll"])) <= 1e-5 * abs(float(g[f"oa{i}_nll"]))
+    m = R.build_model(TINY, 500, 13)
+    with torch.no_grad():
+        m.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+    for i in range(2):
+        src, ts, tgt = (torch.from_numpy(g[f"d3{i}_{k}"]) for k in ("src", "timestep", "tgt"))
+        t_out, nll, tokens = R.sum_nll_ref(m, "d3pm", src, ts, tgt)
+        assert tokens == src.shape[1] and abs(nll - float(g[f"d3{i}_nll"])) <= 1e-5 * abs(float(g[f"d3{i}_nll"]))
