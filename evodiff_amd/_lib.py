@@ -22,7 +22,7 @@ SYMBOLS = ("ed_abi_version", "ed_last_error", "ed_model_create", "ed_model_destr
 
 class EdConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_tokens", "d_embed", "d_model", "d_hidden", "n_layers", "kernel_size",
-                                         "r", "timesteps", "activation")]
+                                         "r", "timesteps", "activation", "causal")]
 
 
 class EdProbeStat(C.Structure):

@@ -261,7 +261,7 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
   }
   double taps = 0;
   for (int t = 0; t < p.ntaps; ++t) {
-    const long off = std::labs((long)(t - p.ntaps / 2) * p.dilation);
+    const long off = std::labs((long)(t - p.center()) * p.dilation);
     taps += off < p.L ? (double)(p.L - off) : 0.0;
   }
   const double flops = 2.0 * p.B * taps * p.N * (double)p.K;
@@ -305,7 +305,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   // LayerNorm that produces it only ever writes the L valid rows, so the zeros survive across steps.
   int max_dil = 1;
   for (const auto& lw : m->layers) max_dil = std::max(max_dil, lw.dilation);
-  const long halo = (long)(c.kernel_size / 2) * max_dil;
+  const long halo = (long)(c.causal ? c.kernel_size - 1 : c.kernel_size / 2) * max_dil;  // causal: all taps look back
   const long pitch = halo + ((L + 255) / 256) * 256L + halo;
   const size_t cbytes = (size_t)B * pitch * c.d_hidden * 4;
   // the element size (and with it every row's byte position) differs between the two precisions
@@ -318,7 +318,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   m->plan.assign((size_t)c.n_layers, LayerPlan{});
   m->plan_s_final = 1;
   long prune_rows = 0;
-  if (m->prune) {
+  if (m->prune && !c.causal) {
     int sset = 1;
     while (sset < (1 << 20) && L % (2 * sset) == 0) sset *= 2;  // largest power of two dividing L
     m->plan_s_final = sset;
@@ -346,7 +346,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   HIP_TRY(need(m->partials, (size_t)32 << 20));
   // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
   m->n_inc = 0;
-  if (m->incremental && c.timesteps == 0) {
+  if (m->incremental && c.timesteps == 0 && !c.causal) {
     int r = 0;
     for (int k = 0; k < ed_model::MAX_INC && k < c.n_layers - 1; ++k) {
       r += (c.kernel_size / 2) * m->layers[k].dilation;
@@ -407,6 +407,7 @@ int run_incremental_layer(ed_model* m, int k, int B, int L, int prec, hipStream_
   if ((rc = run_ln(m, Y, y_bf16, m->Cc[k].p, h, w.ln2_g, w.ln2_b, rows_in, H, scatter_pad, act, s))) return rc;
   GemmProblem gc{m->Cc[k].p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
                  1, rows_out, H, H, c.kernel_size, w.dilation, h, y_bf16};
+  gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
   gc.seq_rows = M_out;
   gc.a_unbounded = true;
   gc.a_sel = win_out;
@@ -476,6 +477,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       if ((rc = run_ln(m, Y, y_bf16, cpad, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
       GemmProblem gc{cpad, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
                      nullptr, B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
+      gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
       if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
       y_pitch = L;
     } else {
@@ -655,6 +657,7 @@ int ed_model_create(const ed_config* cfg, int device, ed_model** out) {
   if (c.r < 1 || c.r > 4096) return fail(ED_EINVAL, "r out of range");
   if (c.timesteps < 0 || c.timesteps > 100000) return fail(ED_EINVAL, "timesteps out of range");
   if (c.activation != 0 && c.activation != 1) return fail(ED_EINVAL, "activation must be 0 (relu) or 1 (gelu)");
+  if (c.causal != 0 && c.causal != 1) return fail(ED_EINVAL, "causal must be 0 or 1");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(ED_EINVAL, "device %d not present (%d devices)", device, ndev);

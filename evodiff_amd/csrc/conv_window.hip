@@ -51,6 +51,7 @@ struct WindowPlan {
   int clip;        // whole-sequence form: a wave skips the taps that move all of its 64 rows outside [0, 256);
                    // the window then starts at position -wofs of the SEQUENCE, whichever tile the workgroup owns
   int na;          // window groups each wave copies per step (1 .. 3)
+  int center;      // tap t reads position l + (t - center) * dilation (2 = 'same' padding, 4 = causal)
 };
 
 // STAMP: diagnostic build that also records the K loop's duration (GemmProblem::stamps).
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
   // ---- fragment addressing: 16 rows x 32 channels per fragment, lane = (row fr, 8-channel chunk fq)
   const int b_rd = (wc * (BN / 2) + fr) * ROW_B;
   const int b_x = (fq ^ ((fr >> 1) & 7)) << 4;
-  const int a_row = lt + wr * 64 + fr + wp.wofs - 2 * d;  // window row of this lane's first activation fragment at tap 0
+  const int a_row = lt + wr * 64 + fr + wp.wofs - wp.center * d;  // window row of this lane's first activation fragment at tap 0
   bf16x8 fact[2][4], fw[RING];
 
   // prologue: window of slice 0 and weights of step 0
@@ -273,16 +274,16 @@ static bool window_plan(const GemmProblem& p, int wm, WindowPlan* wp) {
   // and a launch's results must not depend on which tile height its size selects)
   if (SEQ_ROWS + 4 * d <= WIN_ROWS) {
     const int groups = (bm + 4 * d + 7) / 8;
-    *wp = WindowPlan{groups, 2 * d, 0, NTAPS - 1, 0, (groups + nw * NTAPS - 1) / (nw * NTAPS)};
+    *wp = WindowPlan{groups, p.center() * d, 0, NTAPS - 1, 0, (groups + nw * NTAPS - 1) / (nw * NTAPS), p.center()};
     return wp->na <= 3;
   }
-  if (p.L <= SEQ_ROWS && (d == 32 || d % 64 == 0)) {
+  if (p.center() == NTAPS / 2 && p.L <= SEQ_ROWS && (d == 32 || d % 64 == 0)) {
     const int wofs = d == 32 ? 32 : 0;
     int lo = 0, hi = NTAPS - 1;
     while ((2 - lo) * d >= SEQ_ROWS) ++lo;
     while ((hi - 2) * d >= SEQ_ROWS) --hi;
     const int groups = (SEQ_ROWS + 2 * wofs) / 8, nt = hi - lo + 1;
-    *wp = WindowPlan{groups, wofs, lo, hi, 1, (groups + nw * nt - 1) / (nw * nt)};
+    *wp = WindowPlan{groups, wofs, lo, hi, 1, (groups + nw * nt - 1) / (nw * nt), NTAPS / 2};
     return wp->na <= (wm == 4 ? 2 : 3);
   }
   return false;

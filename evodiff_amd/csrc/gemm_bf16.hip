@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   const int l0 = (tile_m - b * tiles_per_seq) * BM;
   const int n0 = tile_n * BN;
 
-  const int ksteps = g.K / BK, half_taps = g.ntaps / 2;
+  const int ksteps = g.K / BK, half_taps = g.center();
   int tap_lo = 0, tap_hi = g.ntaps - 1;
   while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
   while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
@@ -340,13 +340,14 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
 
 // Shape contract of the tuned kernel.  The caller guarantees the memory contract: A rows
 // [a_row0 - halo, a_row0 + ceil(L/256)*256 + halo) of every sequence are readable, with halo =
-// (ntaps/2)*dilation, and rows outside [0, L) hold zeros whenever ntaps > 1.
+// (ntaps/2)*dilation (causal problems, tap_center = ntaps - 1: (ntaps-1)*dilation rows in front only), and rows outside
+// [0, L) hold zeros whenever ntaps > 1.
 bool gemm_bf16_supported(const GemmProblem& p) {
   if (!p.a_bf16 || p.K % BK != 0 || p.K < BK || p.seq_rows > 0) return false;
   if (p.N % 320 != 0 && p.N % 256 != 0) return false;
   if ((long)p.B * p.L < BM) return false;               // less than one 256-row tile: generic kernel
   if ((long)p.K * 2 * 64 >= (1L << 31)) return false;   // per-lane DMA offsets are 32-bit
-  if (p.ntaps > 1 && p.a_row0 < (long)(p.ntaps / 2) * p.dilation) return false;
+  if (p.ntaps > 1 && p.a_row0 < (long)p.center() * p.dilation) return false;
   if (p.resid && p.out_bf16) return false;
   return true;
 }

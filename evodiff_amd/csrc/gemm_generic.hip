@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   // loader role: thread -> (tile row, 64-byte half of the 128-byte K slice)
   const int lrow = tid >> 1, lhalf = tid & 1;
   const int ksteps = (g.K + KSTEP - 1) / KSTEP;   // the last slice may be half full (K is a multiple of 64 bytes)
-  const int half_taps = g.ntaps / 2;
+  const int half_taps = g.center();
   const bool last_half_empty = (g.K % KSTEP) != 0;
 
   // contiguous range of taps that touch this tile at all

@@ -75,6 +75,9 @@ struct GemmProblem {
   float* partial = nullptr;  //   sums to partial[z][B*L][N] and launch_reduce_partials adds them up in a fixed order
   long long* stamps = nullptr;  // diagnostics (ablate == 7): per tile {shader cycles, 100-MHz ticks} of the K loop
   int ablate = 0;       // diagnostics of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong), 3 = no window form
+  int tap_center = -1;  // tap t reads position l + (t - center) * dilation; -1 = ntaps / 2 ('same' padding, MaskedConv1d),
+                        //   ntaps - 1 = causal (left padding only, MaskedCausalConv1d)
+  __host__ __device__ int center() const { return tap_center >= 0 ? tap_center : ntaps / 2; }
 };
 
 // Reference-quality tile kernel: any shape with K % 32 == 0 (bf16) / K % 16 == 0 (fp32).

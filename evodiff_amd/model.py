@@ -43,15 +43,25 @@ class MaskedConv1d(nn.Conv1d):
         raise RuntimeError("parameter holder only; call the ByteNetLMTime model (HIP path)")
 
 
+class MaskedCausalConv1d(nn.Conv1d):
+    """Parameter holder of the causal convolution ([recalled-upstream] sequence_models.layers.MaskedCausalConv1d:
+    (k-1)*dilation zeros in front of the sequence only, so position l sees positions <= l).  Same weight layout as
+    ``MaskedConv1d``; if a real LR-AR checkpoint nests its keys differently, ``load_state_dict`` is the place."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation=1):
+        super().__init__(in_channels, out_channels, kernel_size, dilation=dilation, padding=0)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder only; call the ByteNetLMTime model (HIP path)")
+
+
 class ByteNetBlock(_ParamOnly):
     """Parameter layout of sequence_models.convolutional.ByteNetBlock (conv, sequence1.{0,2,3}, sequence2.{0,2})."""
 
     def __init__(self, d_in, d_h, d_out, kernel_size, dilation=1, causal=False, rank=None, activation="relu"):
         super().__init__()
-        if causal:
-            raise NotImplementedError("causal ByteNet (LR_AR_*) is outside the hot path (SURVEY.md §8f)")
         act = {"relu": nn.ReLU, "gelu": nn.GELU}[activation]
-        self.conv = MaskedConv1d(d_h, d_h, kernel_size, dilation=dilation)
+        self.conv = (MaskedCausalConv1d if causal else MaskedConv1d)(d_h, d_h, kernel_size, dilation=dilation)
         self.sequence1 = nn.Sequential(nn.LayerNorm(d_in), act(), PositionFeedForward(d_in, d_h, rank=rank),
                                        nn.LayerNorm(d_h), act())
         self.sequence2 = nn.Sequential(nn.LayerNorm(d_h), act(), PositionFeedForward(d_h, d_out, rank=rank))
@@ -120,7 +130,8 @@ class ByteNetLMTime(nn.Module):
         self.last_norm = nn.LayerNorm(d_model)
         self.hparams = dict(n_tokens=n_tokens, d_embed=d_embedding, d_model=d_model,
                             d_hidden=d_model // 2 if slim else d_model, n_layers=n_layers, kernel_size=kernel_size,
-                            r=r, timesteps=int(timesteps or 0), activation=1 if activation == "gelu" else 0)
+                            r=r, timesteps=int(timesteps or 0), activation=1 if activation == "gelu" else 0,
+                            causal=int(bool(causal)))
         self.precision = os.environ.get("EVODIFF_AMD_PRECISION", "bf16")
         self.use_graph = os.environ.get("EVODIFF_AMD_GRAPH", "1") != "0"
         self._handle = None

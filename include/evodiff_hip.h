@@ -51,6 +51,8 @@ typedef struct ed_config {
   int32_t r;            /* 128: dilation of layer n is 2**(n % (log2(r)+1)) (model.py:108-109) */
   int32_t timesteps;    /* 0 = no timestep encoding (OA-DM); 500 for D3PM (model.py:93-94,133) */
   int32_t activation;   /* 1 = exact-erf GELU (the only activation on this path), 0 = ReLU */
+  int32_t causal;       /* 0 = MaskedConv1d ('same' padding); 1 = MaskedCausalConv1d, (k-1)*dilation zeros in front
+                           only (ByteNetBlock(causal=True), model.py:114: the LR_AR_* models) */
 } ed_config;
 
 typedef struct ed_model ed_model;

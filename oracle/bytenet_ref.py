@@ -79,6 +79,23 @@ class MaskedConv1d(nn.Conv1d):
         return super().forward(x.transpose(1, 2)).transpose(1, 2)
 
 
+class MaskedCausalConv1d(nn.Conv1d):
+    """[recalled-upstream sequence_models.layers.MaskedCausalConv1d] Causal dilated Conv1d on channels-last input:
+    (k-1)*dilation zeros in front of the sequence only.
+
+    y[l, o] = b[o] + sum_{tau, c} W[o, c, tau] * x[l + (tau - (k-1)) * dilation, c], zeros for negative positions.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation=1, groups=1, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, dilation=dilation, groups=groups, bias=bias, padding=0)
+        self.left = dilation * (kernel_size - 1)
+
+    def forward(self, x, input_mask=None):
+        if input_mask is not None:
+            x = x * input_mask
+        return super().forward(nn.functional.pad(x.transpose(1, 2), (self.left, 0))).transpose(1, 2)
+
+
 class ByteNetBlock(nn.Module):
     """Residual block: x + seq2(conv(seq1(x))).
 
@@ -90,9 +107,8 @@ class ByteNetBlock(nn.Module):
     def __init__(self, d_in, d_h, d_out, kernel_size, dilation=1, groups=1, causal=False,
                  activation="relu", rank=None):
         super().__init__()
-        if causal:
-            raise NotImplementedError("causal ByteNet (LR_AR_*) is outside the hot path (SURVEY §8f.3)")
-        self.conv = MaskedConv1d(d_h, d_h, kernel_size=kernel_size, dilation=dilation, groups=groups)
+        conv = MaskedCausalConv1d if causal else MaskedConv1d
+        self.conv = conv(d_h, d_h, kernel_size=kernel_size, dilation=dilation, groups=groups)
         act = {"relu": nn.ReLU, "gelu": nn.GELU}[activation]
         self.sequence1 = nn.Sequential(nn.LayerNorm(d_in), act(), PositionFeedForward(d_in, d_h, rank=rank),
                                        nn.LayerNorm(d_h), act())
@@ -192,11 +208,13 @@ MASK_ID = MSA_ALPHABET.index(MASK)
 
 def build_model(cfg: dict, timesteps: Optional[int] = None, seed: Optional[int] = 0) -> ByteNetLMTime:
     """Constructor call of pretrained.py:39-42 (n_tokens=31, padding_idx=mask, final_ln=True,
-    tie_weights=False, dropout=0), weights = PyTorch default init under ``torch.manual_seed(seed)``."""
+    tie_weights=False, dropout=0), weights = PyTorch default init under ``torch.manual_seed(seed)``.
+    Optional cfg keys ``n_tokens`` (30 for the PROTEIN_ALPHABET models, pretrained.py:164-205) and ``causal``
+    (LR_AR_*, :170-171)."""
     if seed is not None:
         torch.manual_seed(seed)
-    return ByteNetLMTime(len(MSA_ALPHABET), cfg["d_embed"], cfg["d_model"], cfg["n_layers"],
-                         cfg["kernel_size"], cfg["r"], causal=False, padding_idx=MASK_ID, rank=None,
+    return ByteNetLMTime(cfg.get("n_tokens", len(MSA_ALPHABET)), cfg["d_embed"], cfg["d_model"], cfg["n_layers"],
+                         cfg["kernel_size"], cfg["r"], causal=cfg.get("causal", False), padding_idx=MASK_ID, rank=None,
                          dropout=0.0, tie_weights=False, final_ln=True, slim=cfg.get("slim", True),
                          activation=cfg.get("activation", "relu"), timesteps=timesteps).eval()
 

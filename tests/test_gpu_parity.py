@@ -36,8 +36,9 @@ def dev():
 
 def product_model(oracle_model, cfg, timesteps=None, precision="fp32"):
     from evodiff_amd.model import ByteNetLMTime
-    m = ByteNetLMTime(len(R.MSA_ALPHABET), cfg["d_embed"], cfg["d_model"], cfg["n_layers"], cfg["kernel_size"],
-                      cfg["r"], causal=False, padding_idx=R.MASK_ID, rank=None, dropout=0.0, tie_weights=False,
+    m = ByteNetLMTime(cfg.get("n_tokens", len(R.MSA_ALPHABET)), cfg["d_embed"], cfg["d_model"], cfg["n_layers"],
+                      cfg["kernel_size"], cfg["r"], causal=cfg.get("causal", False), padding_idx=R.MASK_ID, rank=None,
+                      dropout=0.0, tie_weights=False,
                       final_ln=True, slim=cfg["slim"], activation=cfg["activation"], timesteps=timesteps)
     m.load_state_dict(oracle_model.state_dict())
     m.precision = precision
@@ -418,6 +419,7 @@ def test_38m_config5_full_size_batch_invariance(dev):
     m.precision = "bf16"
     m.set_option("min_tuned_tiles", 0)
     m.set_option("prune", 0)
+    m.set_option("incremental", 0)            # (the number of incremental leading layers depends on the batch size)
     B, L, n = 1024, 1024, 2
     order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
     uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32)).to(dev)
@@ -431,6 +433,7 @@ def test_38m_config5_full_size_batch_invariance(dev):
     # the small batch against the oracle (same seeded default init), first step, default execution options
     m.set_option("min_tuned_tiles", 130)
     m.set_option("prune", 1)
+    m.set_option("incremental", 1)
     torch.manual_seed(0)
     oracle = R.build_model(R.MODEL_CONFIGS["38M"], None, None)
     oracle.load_state_dict(m.state_dict())
@@ -564,3 +567,31 @@ def test_scoring_against_reference_losses(golden_dir, dev, precision, tol):
     from evodiff_amd._lib import EvoDiffHipError
     with pytest.raises(EvoDiffHipError, match="targets"):
         m.score_nll(src, torch.zeros(3, dtype=torch.long), tgt, n_classes=21)   # pad / mask ids are >= 21
+
+
+@pytest.mark.parametrize("base,B,L", [(MID, 2, 37), (MID, 3, 300), (TINY_WIDE, 1, 513), (BIG512, 3, 256),
+                                      (BIG640, 4, 512), (BIG640, 16, 130), (BIG640, 64, 256)])
+def test_causal_forward_vs_oracle(dev, base, B, L):
+    """the LR-AR / CARP variants (pretrained.py:164-205): 30-token alphabet, and causal=True =>
+    MaskedCausalConv1d (all taps look back).  Every convolution kernel family takes the causal form: the small-tile
+    kernel, the per-tap tuned kernel (dilation >= 32) and the windowed one (dilation <= 16), 128- and 256-row tiles.
+    [recalled-upstream: parity of the causal convolution itself is unpinned, the oracle restates it.]"""
+    cfg = dict(base, n_tokens=30, causal=True)
+    oracle = R.build_model(cfg, None, 31)
+    m = product_model(oracle, cfg)
+    x = torch.from_numpy(np.random.default_rng(B * 1000 + L).integers(0, 30, (B, L)))
+    with torch.no_grad():
+        ref = oracle(x, torch.zeros(B, dtype=torch.long)).numpy()
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    assert ref.shape == (B, L, 30)
+    assert rel_err(m(x.to(dev), t).cpu().numpy(), ref) < FP32_TOL
+    m.precision = "bf16"
+    m.set_option("min_tuned_tiles", 0)            # tuned kernels wherever the shape allows
+    got = m(x.to(dev), t)
+    assert rel_err(got.cpu().numpy(), ref) < BF16_TOL
+    # causality: changing the tokens after position p leaves the logits up to p bit-identical
+    p = L // 2
+    x2 = x.clone()
+    x2[:, p + 1:] = (x2[:, p + 1:] + 7) % 30
+    got2 = m(x2.to(dev), t)
+    assert torch.equal(got[:, :p + 1], got2[:, :p + 1]) and not torch.equal(got[:, p + 1:], got2[:, p + 1:])
