@@ -14,6 +14,9 @@ MASK = "#"
 START = "@"
 MSA_PAD = "!"
 SEP = "/"
+PAD = GAP
+SPECIALS = STOP + GAP + MASK + START
+PROTEIN_ALPHABET = ALL_AAS + SPECIALS          # 30 symbols [recalled-upstream]: the CARP / LR-AR vocabulary
 MSA_AAS = ALL_AAS + GAP
 MSA_ALPHABET = ALL_AAS + GAP + STOP + MASK + START + MSA_PAD
 AAINDEX_ALPHABET = "ARNDCQEGHILKMFPSTWYV"

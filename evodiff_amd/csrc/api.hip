@@ -114,6 +114,10 @@ struct ed_model {
   int n_inc = 0;
   int inc_r[MAX_INC + 1] = {0, 0, 0, 0, 0};  // inc_r[k + 1] = r_k; inc_r[0] = 0 (the changed token itself)
   DevBuf Xc[MAX_INC + 1], Cc[MAX_INC];
+  // Autoregressive sampling of a causal model (ed_ar_sample): the convolution inputs of EVERY layer are kept (past rows
+  // never change), a step computes one new row per sequence and layer.  Car[k]: [B][conv_pitch][d_hidden].
+  std::vector<DevBuf> Car;
+  int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   bool prune = true;           // ED_OPT_PRUNE
@@ -375,7 +379,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
 
 // Variants of a step: every position with no state kept (forward, D3PM), every position while filling the caches of
 // the incremental layers (first OA-DM step of a call), and the incremental step proper.
-enum { STEP_PLAIN = 0, STEP_FILL = 1, STEP_INCR = 2 };
+enum { STEP_PLAIN = 0, STEP_FILL = 1, STEP_INCR = 2, STEP_AR = 3 };
 
 // One incremental leading layer k (STEP_INCR): the rows within r_{k-1} of the changed position go through
 // LN1 / PFF1 / LN2 into the cached convolution input, the rows within r_k through conv / LN3 / PFF2 into the cached
@@ -548,13 +552,63 @@ int check_shape(const ed_model* m, int B, int L, int prec) {
   return ED_OK;
 }
 
-enum { MODE_OADM = 0, MODE_D3PM = 1 };
+enum { MODE_OADM = 0, MODE_D3PM = 1, MODE_AR = 2 };
+
+// One autoregressive step of a causal model (generate.py:238-244 without re-running the prefix): the token at position
+// p = order[step] is new; every layer computes row p only - its 1x1 projections on the B new rows, its convolution
+// from the cached rows p - tau*d of its own input - and the draw from row p's logits becomes token p + 1.
+int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStream_t s) {
+  const ed_config& c = m->cfg;
+  const int D = c.d_model, H = c.d_hidden;
+  const bool h = prec == ED_PREC_BF16;
+  const int act = c.activation == 1 ? 1 : 2;
+  const PosBit pos = PosBit::window(m->order.as<int>(), m->state.as<StepState>(), 0, L - 1, /*lag=*/0);
+  float* x = m->X.as<float>();   // residual stream: one row per sequence
+  void* A = m->Abuf.p;
+  void* Y = m->Ybuf.p;
+  int rc;
+  {
+    Probe pr(m, s);
+    LAUNCH_TRY(pr.begin());
+    LAUNCH_TRY(launch_embed_gather_rows(m->tok.as<int64_t>(), m->emb_table.as<float>(), x, B, L, D, c.n_tokens, pos, s,
+                                        /*compact=*/true));
+    LAUNCH_TRY(pr.end(ED_K_EMBED, 0.0, (double)B * (8 + D * 4.0)));
+  }
+  for (int k = 0; k < c.n_layers; ++k) {
+    const LayerW& w = m->layers[k];
+    if ((rc = run_ln(m, x, false, A, h, w.ln1_g, w.ln1_b, B, D, LnRowMap::plain(B), act, s))) return rc;
+    GemmProblem g1{A, B, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, B, H, D, 1, 1, h, h};
+    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
+    const LnRowMap to_cache{1, 1, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, pos};
+    if ((rc = run_ln(m, Y, h, m->Car[k].p, h, w.ln2_g, w.ln2_b, B, H, to_cache, act, s))) return rc;
+    GemmProblem gc{m->Car[k].p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
+                   nullptr, 1, B, H, H, c.kernel_size, w.dilation, h, h};
+    gc.tap_center = c.kernel_size - 1;
+    gc.seq_rows = 1;
+    gc.a_unbounded = true;   // rows p - tau*d >= -halo: real zero padding in front of every sequence
+    gc.a_sel = pos;
+    gc.out_pitch = 1;
+    if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+    if ((rc = run_ln(m, Y, h, A, h, w.ln3_g, w.ln3_b, B, H, LnRowMap::plain(B), act, s))) return rc;
+    GemmProblem g2{A, B, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x, x, 1, B, D, H, 1, 1, h, false};
+    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s))) return rc;
+  }
+  Probe pr(m, s);
+  LAUNCH_TRY(pr.begin());
+  LAUNCH_TRY(launch_final_oadm(x, 1, 30, m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),
+                               m->order.as<int>(), m->uni.as<float>(), m->state.as<StepState>(), probs, B, L, D, n, s,
+                               /*write_shift=*/1));
+  LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * n * D, (double)B * D * 4.0));
+  LAUNCH_TRY(launch_advance_step(m->state.as<StepState>(), s));
+  return ED_OK;
+}
 
 // One sampling step on the model-owned buffers (tok/order/uni/qbuf/state).
 int run_step(ed_model* m, int mode, int variant, int B, int L, int n, int prec, float* probs, double* post,
              hipStream_t s) {
   const ed_config& c = m->cfg;
   int rc;
+  if (mode == MODE_AR) return run_ar_step(m, B, L, n, prec, probs, s);
   if (m->n_inc == 0) variant = STEP_PLAIN;
   if ((rc = run_embed(m, m->tok.as<int64_t>(), nullptr, B, L, variant, s))) return rc;
   const bool pruned = mode == MODE_OADM && m->plan_s_final > 1;
@@ -617,7 +671,8 @@ int run_loop(ed_model* m, int mode, int B, int L, int n, int n_steps, int prec, 
   const bool inc = mode == MODE_OADM && m->n_inc > 0;
   hipGraphExec_t exec_first = nullptr, exec_rest = nullptr;
   if (use_graph && !traced) {
-    int rc = get_graph(m, mode, inc ? STEP_FILL : STEP_PLAIN, B, L, n, prec, nullptr, nullptr, &exec_first);
+    int rc = get_graph(m, mode, mode == MODE_AR ? STEP_AR : inc ? STEP_FILL : STEP_PLAIN, B, L, n, prec, nullptr, nullptr,
+                       &exec_first);
     if (rc) return rc;
     exec_rest = exec_first;
     if (inc && n_steps > 1 && (rc = get_graph(m, mode, STEP_INCR, B, L, n, prec, nullptr, nullptr, &exec_rest))) return rc;
@@ -894,6 +949,54 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
   HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
   if ((rc = run_loop(m, MODE_OADM, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  return ED_OK;
+}
+
+int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, int B, int L, int n_steps, int n_draw,
+                 float* probs_dev, int precision, int use_graph, void* stream) {
+  int rc = check_shape(m, B, L, precision);
+  if (rc) return rc;
+  const ed_config& c = m->cfg;
+  if (!c.causal) return fail(ED_ESTATE, "autoregressive sampling needs a causal model (cfg.causal = 1)");
+  if (c.timesteps > 0) return fail(ED_ESTATE, "autoregressive sampling is for models without timestep encoding");
+  if (!tokens_dev || !uniforms_dev) return fail(ED_EINVAL, "null tokens/uniforms pointer");
+  if (n_steps < 0 || n_steps > L - 1) return fail(ED_EINVAL, "n_steps must be in [0, L-1]: step s writes position s+1");
+  if (n_draw < 1 || n_draw > c.n_tokens) return fail(ED_EINVAL, "n_draw must be in [1, n_tokens]");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(m->device));
+  // the shared workspace only has to hold one row per sequence here, but its convolution layout (pitch, halo) is the
+  // one the caches use: size it for (B, L) like any other call
+  if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
+  if (n_steps == 0) return ED_OK;
+  {
+    const size_t cbytes = (size_t)B * m->conv_pitch * c.d_hidden * (precision == ED_PREC_BF16 ? 2 : 4);
+    bool fresh = m->ar_B != B || m->ar_L != L || m->ar_prec != precision || (int)m->Car.size() != c.n_layers;
+    if ((int)m->Car.size() != c.n_layers) m->Car.resize((size_t)c.n_layers);
+    for (auto& buf : m->Car) {
+      if (cbytes > buf.bytes) {
+        fresh = true;
+        HIP_TRY(buf.ensure(cbytes));
+      }
+    }
+    if (fresh) {  // zero halo in front of every sequence; rows >= 0 are written before they are read
+      for (auto& buf : m->Car) HIP_TRY(hipMemsetAsync(buf.p, 0, buf.bytes, s));
+      m->drop_graphs();
+      m->ar_B = B; m->ar_L = L; m->ar_prec = precision;
+    }
+    const size_t ob = m->order.bytes, ub = m->uni.bytes;
+    HIP_TRY(m->order.ensure((size_t)n_steps * 4));
+    HIP_TRY(m->uni.ensure((size_t)n_steps * B * 4));
+    if (m->order.bytes != ob || m->uni.bytes != ub) m->drop_graphs();
+  }
+  std::vector<int32_t> ord((size_t)n_steps);
+  for (int i = 0; i < n_steps; ++i) ord[i] = i;  // step i extends the sequence from position i
+  HIP_TRY(hipMemcpyAsync(m->order.p, ord.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // (ord is a stack-lifetime host buffer)
+  HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)n_steps * B * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
+  if ((rc = run_loop(m, MODE_AR, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s))) return rc;
   HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
   return ED_OK;
 }

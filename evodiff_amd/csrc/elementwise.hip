@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void final_oadm_kernel(const float* __restrict_
                                                         int64_t* tokens, const int* __restrict__ order,
                                                         const float* __restrict__ uniforms, const StepState* state,
                                                         float* probs, int B, int L, int D, int n_draw,
-                                                        int x_rows_per_seq, int x_shift) {
+                                                        int x_rows_per_seq, int x_shift, int write_shift) {
   const int lane = threadIdx.x, b = blockIdx.x;
   const int step = state->step;
   const int pos = order[step];
@@ -480,7 +480,8 @@ __global__ __launch_bounds__(64) void final_oadm_kernel(const float* __restrict_
   const unsigned long long below = __ballot(lane < n_draw && mycdf <= thr);
   int idx = __popcll(below);
   if (idx > n_draw - 1) idx = n_draw - 1;
-  if (lane == 0) tokens[row] = idx;
+  // write_shift = 1 (autoregressive steps, generate.py:241-244): the draw from position pos is the NEXT token
+  if (lane == 0 && pos + write_shift < L) tokens[row + write_shift] = idx;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -553,19 +554,20 @@ hipError_t launch_embed(const int64_t* tokens, const int64_t* tvec, const StepSt
 
 __global__ __launch_bounds__(64) void embed_gather_rows_kernel(const int64_t* __restrict__ tokens,
                                                                const float* __restrict__ table, float* __restrict__ X,
-                                                               int L, int D, int n_tokens, PosBit sel) {
+                                                               int L, int D, int n_tokens, PosBit sel, bool compact) {
   const long row = (long)blockIdx.x * L + sel.get();
   long tok = tokens[row];
   if (tok < 0 || tok >= n_tokens) tok = n_tokens - 1;
   const float4* src = (const float4*)(table + tok * D);
-  float4* dst = (float4*)(X + row * D);
+  float4* dst = (float4*)(X + (compact ? (long)blockIdx.x : row) * D);
   for (int c = threadIdx.x; c < D / 4; c += 64) dst[c] = src[c];
 }
 
 hipError_t launch_embed_gather_rows(const int64_t* tokens, const float* table, float* X, int B, int L, int D,
-                                    int n_tokens, PosBit sel, hipStream_t stream) {
+                                    int n_tokens, PosBit sel, hipStream_t stream, bool compact) {
   if (D % 4 != 0 || B <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(embed_gather_rows_kernel, dim3(B), dim3(64), 0, stream, tokens, table, X, L, D, n_tokens, sel);
+  hipLaunchKernelGGL(embed_gather_rows_kernel, dim3(B), dim3(64), 0, stream, tokens, table, X, L, D, n_tokens, sel,
+                     compact);
   return hipGetLastError();
 }
 
@@ -663,12 +665,12 @@ hipError_t launch_final_nll(const float* X, const float* gamma, const float* bet
 hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
                              const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
                              const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
-                             int n_draw, hipStream_t stream) {
+                             int n_draw, hipStream_t stream, int write_shift) {
   if (D % 4 != 0 || n_draw > 64 || n_draw < 1 || B <= 0) return hipErrorInvalidValue;
   const dim3 grid(B), block(64);
 #define ED_CALL(N)                                                                                             \
   hipLaunchKernelGGL((final_oadm_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, tokens, order, \
-                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift)
+                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift, write_shift)
   ED_NCH_DISPATCH(D, ED_CALL);
 #undef ED_CALL
   return hipGetLastError();

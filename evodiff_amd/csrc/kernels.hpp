@@ -26,7 +26,8 @@ struct StepState {
 // inside a captured graph.
 //  - bit field (maxstart < 0): bits [shift, shift + log2(mask + 1)) of order[step], the position the step fills;
 //  - window (maxstart >= 0): first row of the window of rows that changed since the previous step, i.e. that lie
-//    within `radius` of order[step - 1] (the position the previous step filled), clamped to [0, maxstart].
+//    within `radius` of order[step - lag], clamped to [0, maxstart]: lag = 1 for OA-DM (the position the previous
+//    step filled), lag = 0 for autoregressive steps (the position this step extends the sequence from).
 struct PosBit {
   const int* order = nullptr;
   const StepState* state = nullptr;
@@ -34,15 +35,16 @@ struct PosBit {
   int mask = 0;
   int radius = 0;
   int maxstart = -1;
+  int lag = 1;
   __device__ __forceinline__ int get() const {
     if (!order) return 0;
     if (maxstart < 0) return (order[state->step] >> shift) & mask;
-    const int s = order[state->step - 1] - radius;
+    const int s = order[state->step - lag] - radius;
     return s < 0 ? 0 : (s > maxstart ? maxstart : s);
   }
-  static PosBit window(const int* order, const StepState* state, int radius, int maxstart) {
+  static PosBit window(const int* order, const StepState* state, int radius, int maxstart, int lag = 1) {
     PosBit p;
-    p.order = order; p.state = state; p.radius = radius; p.maxstart = maxstart;
+    p.order = order; p.state = state; p.radius = radius; p.maxstart = maxstart; p.lag = lag;
     return p;
   }
 };
@@ -112,8 +114,9 @@ hipError_t launch_embed_gather(const int64_t* tokens, const float* table, float*
                                hipStream_t stream);
 
 // X[b*L + sel] = table[tokens[b*L + sel]] for every sequence b: the one row per sequence that changed.
+// compact: X holds ONE row per sequence (row b) instead of L (row b*L + position)
 hipError_t launch_embed_gather_rows(const int64_t* tokens, const float* table, float* X, int B, int L, int D,
-                                    int n_tokens, PosBit sel, hipStream_t stream);
+                                    int n_tokens, PosBit sel, hipStream_t stream, bool compact = false);
 
 // Row maps of the LayerNorm kernel: logical row r = (b, m), m < rows_per_seq, is read from row
 // in_row0 + b*in_pitch + m*in_mul + in_sel.get() and written to row out_row0 + b*out_pitch + m + out_sel.get().
@@ -143,7 +146,7 @@ hipError_t launch_final_logits(const float* X, const float* gamma, const float* 
 hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
                              const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
                              const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
-                             int n_draw, hipStream_t stream);
+                             int n_draw, hipStream_t stream, int write_shift = 0);
 
 // D3PM step tail (generate.py:279-298): softmax over K, fp64 posterior with Q[t] / Qbar[t-1], one draw per
 // position, in place on tokens.

@@ -98,6 +98,33 @@ def generate_oaardm_order_opt(model, tokenizer, seq_len, penalty=None, batch_siz
     return sample, _strings(tokenizer, sample)
 
 
+def generate_autoreg(model, tokenizer, samples=100, batch_size=1, max_seq_len=1024, device='cuda', *, uniforms=None):
+    """``generate.py:217-256`` for the causal LR-AR models: every sequence starts from the START token and grows by
+    one drawn token per step until STOP or ``max_seq_len``.  ``batch_size`` sequences are sampled side by side (the
+    reference's loop takes one at a time whatever ``batch_size`` says); the GPU loop always runs ``max_seq_len`` steps
+    and the sequence is cut at its first STOP afterwards - what follows a token cannot influence what precedes it in
+    a causal model.  As there, the returned sequences drop the START token and the LAST generated token (the STOP, or
+    the final residue when ``max_seq_len`` is reached, :252-254).  ``uniforms`` (samples, max_seq_len) pre-drawn."""
+    start, stop = tokenizer.start_id, tokenizer.stop_id
+    if uniforms is None:
+        uniforms = torch.rand((samples, max_seq_len), dtype=torch.float32, device=device)
+    uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device)
+    sample_out, untokenized_out = [], []
+    with torch.no_grad():
+        for s0 in range(0, samples, max(1, batch_size)):
+            nb = min(max(1, batch_size), samples - s0)
+            sample = torch.full((nb, max_seq_len + 1), start, dtype=torch.long, device=device)
+            model.ar_sample(sample, uniforms[s0:s0 + nb].t().contiguous(), n_steps=max_seq_len)
+            host = sample.cpu()
+            for row in host:
+                hits = (row[1:] == stop).nonzero()
+                end = int(hits[0]) + 2 if len(hits) else max_seq_len + 1      # one past the STOP / the last token
+                seq = row[1:end - 1].to(device)
+                sample_out.append(seq)
+                untokenized_out.append(tokenizer.untokenize(seq))
+    return sample_out, untokenized_out
+
+
 def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, batch_size=3, device='cuda', *, uniforms=None,
                   start=None):
     """Start from uniformly random tokens and run the reverse chain t = timesteps-1 ... 1."""

@@ -272,6 +272,26 @@ class ByteNetLMTime(nn.Module):
                                           int(self.use_graph), stream))
         return probs
 
+    def ar_sample(self, sample, uniforms, n_steps=None, n_draw=None, return_probs=False):
+        """Loop of generate_autoreg (generate.py:238-244) on the GPU for a causal model: ``sample`` (B, L) holds the
+        START token in column 0; columns 1 .. n_steps are filled in place, one cached-convolution step each."""
+        handle = self.hip_handle(sample.device)
+        lib = _lib.load()
+        B, L = sample.shape
+        n_steps = L - 1 if n_steps is None else int(n_steps)
+        n_draw = self.hparams["n_tokens"] if n_draw is None else int(n_draw)
+        assert sample.dtype == torch.long and sample.is_contiguous()
+        uniforms = uniforms.to(device=sample.device, dtype=torch.float32).contiguous()
+        if uniforms.shape != (n_steps, B):
+            raise ValueError("uniforms must be (n_steps, B)")
+        probs = torch.empty((n_steps, B, n_draw), dtype=torch.float32, device=sample.device) if return_probs else None
+        stream = torch.cuda.current_stream(sample.device).cuda_stream
+        with torch.cuda.device(sample.device):
+            _lib.check(lib.ed_ar_sample(handle, sample.data_ptr(), uniforms.data_ptr(), B, L, n_steps, n_draw,
+                                        probs.data_ptr() if return_probs else None, self._prec(),
+                                        int(self.use_graph), stream))
+        return probs
+
     def d3pm_sample(self, sample, Q, Q_bar, uniforms, K, t_start=None, n_steps=None, return_post=False):
         """Loop of generate_d3pm (generate.py:274-298) on the GPU; ``sample`` (B, L) is updated in place."""
         handle = self.hip_handle(sample.device)

@@ -13,12 +13,12 @@ import os
 import torch
 
 from .collaters import D3PMCollater, OAMaskCollater
-from .constants import MSA_ALPHABET
+from .constants import ALL_AAS, MSA_ALPHABET, PAD, PROTEIN_ALPHABET
 from .model import ByteNetLMTime
 from .utils import DEFAULT_BLOSUM, Tokenizer, download_model
 
 _CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
-_CHECKPOINT_STEMS = ("oaar", "d3pm-blosum", "d3pm-uniform")
+_CHECKPOINT_STEMS = ("oaar", "d3pm-blosum", "d3pm-uniform", "lrar", "carp")
 
 
 def _config_path(name):
@@ -95,3 +95,43 @@ def OA_DM_640M(path_to_checkpoints=None, random_init=False):
 
 def OA_DM_38M(path_to_checkpoints=None, random_init=False):
     return _oadm("oaar-38M", "config38M.json", path_to_checkpoints, random_init)
+
+
+class _ThirdPartyCollater(object):
+    """``sequence_models.collaters.LMCollater`` (pretrained.py:167) is third-party training code; not restated."""
+
+    def __init__(self, alphabet):
+        self.alphabet = alphabet
+
+    def __call__(self, sequences):
+        raise NotImplementedError("LMCollater belongs to sequence_models (training / causal-mask scoring); not in this build")
+
+
+def _protein_alphabet_model(model_name, config, causal, path_to_checkpoints, random_init):
+    tokenizer = Tokenizer(protein_alphabet=PROTEIN_ALPHABET, all_aas=ALL_AAS, pad=PAD)
+    model, tokenizer = load_sequence_checkpoint(model_name, _config_path(config), diffusion_timesteps=None,
+                                                tokenizer=tokenizer, causal=causal, n_tokens=len(PROTEIN_ALPHABET),
+                                                path_to_checkpoints=path_to_checkpoints, random_init=random_init)
+    return model, tokenizer
+
+
+def LR_AR_640M(path_to_checkpoints=None, random_init=False):
+    """pretrained.py:164-173: causal ByteNet over the 30-token PROTEIN_ALPHABET, sampled by ``generate_autoreg``."""
+    model, tokenizer = _protein_alphabet_model("lrar-640M", "config640M.json", True, path_to_checkpoints, random_init)
+    return model, _ThirdPartyCollater(PROTEIN_ALPHABET), tokenizer, "causal-mask"
+
+
+def LR_AR_38M(path_to_checkpoints=None, random_init=False):
+    model, tokenizer = _protein_alphabet_model("lrar-38M", "config38M.json", True, path_to_checkpoints, random_init)
+    return model, _ThirdPartyCollater(PROTEIN_ALPHABET), tokenizer, "causal-mask"
+
+
+def CARP_38M(path_to_checkpoints=None, random_init=False):
+    """pretrained.py:186-194: the OA-DM architecture over PROTEIN_ALPHABET (masked-LM pretraining); scheme 'mask'."""
+    model, tokenizer = _protein_alphabet_model("carp-38M", "config38M.json", False, path_to_checkpoints, random_init)
+    return model, OAMaskCollater(tokenizer=tokenizer), tokenizer, "mask"
+
+
+def CARP_640M(path_to_checkpoints=None, random_init=False):
+    model, tokenizer = _protein_alphabet_model("carp-640M", "config640M.json", False, path_to_checkpoints, random_init)
+    return model, OAMaskCollater(tokenizer=tokenizer), tokenizer, "mask"

@@ -119,6 +119,18 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
                    int B, int L, int n_steps, int n_draw, float* probs_dev, int precision, int use_graph,
                    void* stream);
 
+/* Replaces: the per-sequence loop of generate_autoreg (evodiff/generate.py:229-250) for a causal model (LR_AR_*):
+ * tokens_dev (B, L) holds the START token at position 0 of every row; step s = 0 .. n_steps-1 takes the logits at
+ * position s (softmax over the first n_draw of them, generate.py:241-243 uses all), draws token s+1 per sequence by
+ * the inverse CDF at uniforms_dev[s][b] and writes it to position s+1 (n_steps <= L-1).  Where the reference runs the
+ * model again on the whole growing prefix at every step, this keeps each layer's convolution input of the past
+ * positions (they cannot change: every tap looks back) and computes ONE new row per sequence, layer and step.
+ * The loop does not stop at the STOP token: what follows it does not influence what precedes it, so the caller cuts
+ * the sequence there (evodiff_amd/generate.py::generate_autoreg).  probs_dev (n_steps, B, n_draw) may be NULL.
+ * ED_ESTATE unless cfg.causal = 1 and cfg.timesteps = 0. */
+int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, int B, int L, int n_steps, int n_draw,
+                 float* probs_dev, int precision, int use_graph, void* stream);
+
 /* Replaces: the loop of generate_d3pm (evodiff/generate.py:274-298).
  * tokens_dev int64 (B, L) in/out = x_t on entry; Q_dev / Qbar_dev fp64 (timesteps, K, K) as returned by
  * Tokenizer.q_blosum_schedule / q_random_schedule (evodiff/utils.py:216-249); runs n_steps steps

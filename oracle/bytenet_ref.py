@@ -445,6 +445,24 @@ def generate_oaardm_order_opt_ref(model, seq_len, batch_size, uniforms, n_draw: 
 
 
 @torch.no_grad()
+def generate_autoreg_ref(model, start_id: int, stop_id: int, max_seq_len: int, uniforms, trace=None):
+    """One sequence of generate.py:229-256: the model runs on the whole growing prefix at every step, the next token
+    is drawn from softmax over ALL logits of the last position (:241-243) by the inverse CDF at ``uniforms[i]``.
+    Returns the tokens without START and without the last generated one (:252-254)."""
+    sample = torch.full((1, 1), start_id, dtype=torch.long)
+    timestep = torch.zeros(1, dtype=torch.long)
+    for i in range(max_seq_len):
+        p = torch.softmax(model(sample, timestep)[:, -1, :], dim=1)
+        tok, margin = inverse_cdf(p, uniforms[i].reshape(1))
+        sample = torch.cat((sample, tok.reshape(1, 1)), dim=1)
+        if trace is not None:
+            trace.append({"p": p[0].clone(), "tok": int(tok), "margin": float(margin)})
+        if int(tok) == stop_id:
+            break
+    return sample[0, 1:-1]
+
+
+@torch.no_grad()
 def sum_nll_ref(model, scheme: str, src, timestep, tgt, mask=None):
     """The model call and loss of sum_nll_mask (analysis/sequence_perp.py:125-155) for the ByteNet schemes.
     'mask': OAMaskedCrossEntropyLoss(reweight=False) (losses.py:46-70): summed CE over the masked positions, all

@@ -595,3 +595,64 @@ def test_causal_forward_vs_oracle(dev, base, B, L):
     x2[:, p + 1:] = (x2[:, p + 1:] + 7) % 30
     got2 = m(x2.to(dev), t)
     assert torch.equal(got[:, :p + 1], got2[:, :p + 1]) and not torch.equal(got[:, p + 1:], got2[:, p + 1:])
+
+
+@pytest.mark.parametrize("base,precision,max_len", [(TINY_WIDE, "fp32", 48), (TINY, "fp32", 300), (TINY_WIDE, "bf16", 48)])
+def test_autoregressive_sampler_vs_oracle(dev, base, precision, max_len):
+    """generate_autoreg (generate.py:217-256) on a causal model.  The oracle re-runs the whole
+    growing prefix at every step like the reference; ed_ar_sample computes one new row per layer from cached
+    convolution inputs (max_len = 300 reaches back over every dilation of the schedule).  Three sequences side by
+    side, each checked against its own oracle run: per-step probabilities, and tokens up to the first draw that is
+    closer to a category boundary than the margin."""
+    from evodiff_amd.generate import generate_autoreg
+    from evodiff_amd.utils import Tokenizer
+    from evodiff_amd.constants import ALL_AAS, PAD, PROTEIN_ALPHABET
+    cfg = dict(base, n_tokens=30, causal=True)
+    oracle = R.build_model(cfg, None, 41)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(4.0)
+    m = product_model(oracle, cfg, precision=precision)
+    tok = Tokenizer(protein_alphabet=PROTEIN_ALPHABET, all_aas=ALL_AAS, pad=PAD)
+    assert (tok.start_id, tok.stop_id, tok.mask_id) == (29, 26, 28)
+    n = 3
+    uni = torch.from_numpy(np.random.default_rng(17).random((n, max_len), dtype=np.float32))
+    sample = torch.full((n, max_len + 1), tok.start_id, dtype=torch.long, device=dev)
+    probs = m.ar_sample(sample, uni.t().contiguous().to(dev), n_steps=max_len, return_probs=True).cpu()
+    margin = DRAW_MARGIN_FP32 if precision == "fp32" else DRAW_MARGIN_BF16
+    p_tol = 1e-5 if precision == "fp32" else 5e-2
+    seqs, _ = generate_autoreg(m, tok, samples=n, batch_size=2, max_seq_len=max_len, device=dev, uniforms=uni)
+    checked = 0
+    for b in range(n):
+        trace = []
+        # the per-step check runs past STOP (the GPU loop does too); the reference's own stopping rule gives `ref`
+        R.generate_autoreg_ref(oracle, tok.start_id, -1, max_len, uni[b], trace=trace)
+        ref = R.generate_autoreg_ref(oracle, tok.start_id, tok.stop_id, max_len, uni[b])
+        safe = len(trace)
+        for s, tr in enumerate(trace):
+            assert float((probs[s, b] - tr["p"]).abs().max()) < p_tol, (b, s)
+            if tr["margin"] <= margin:
+                safe = s          # this draw may legitimately differ, and everything after it follows another path
+                break
+            assert int(sample[b, s + 1]) == tr["tok"], (b, s)
+        checked += safe
+        if safe == len(trace):    # whole sequence comparable: the cut at STOP and the dropped last token too
+            assert torch.equal(seqs[b].cpu(), ref), b
+    if precision == "fp32":
+        assert checked >= max_len
+    # teacher-forced along the GPU's own path (one causal oracle forward over the finished rows gives every step's
+    # distribution): per-step probabilities, and each token is the inverse-CDF draw from the GPU's probabilities
+    with torch.no_grad():
+        p_ref = torch.softmax(oracle(sample.cpu(), torch.zeros(n, dtype=torch.long)), dim=-1)
+    for b in range(n):
+        assert float((probs[:, b] - p_ref[b, :max_len]).abs().max()) < p_tol
+        idx, mg = R.inverse_cdf(probs[:, b], uni[b])
+        ok = mg > 1e-6
+        assert torch.equal(idx[ok], sample[b, 1:].cpu()[ok]) and int(ok.sum()) > max_len // 2
+    # graph replay and eager launches agree bit for bit; a second call reuses the caches' zero padding
+    m.use_graph = False
+    again = torch.full((n, max_len + 1), tok.start_id, dtype=torch.long, device=dev)
+    m.ar_sample(again, uni.t().contiguous().to(dev), n_steps=max_len)
+    assert torch.equal(again, sample)
+    with pytest.raises(Exception, match="causal"):
+        product_model(R.build_model(dict(base, n_tokens=30), None, 41), dict(base, n_tokens=30)).ar_sample(
+            again, uni.t().contiguous().to(dev), n_steps=max_len)

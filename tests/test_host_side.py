@@ -205,3 +205,21 @@ def test_collaters_reproduce_the_reference_draws(golden_dir):
         out = D3PMCollater(tok_u, 500, Q, Q_bar)([(seq,)])
         assert np.array_equal(out[0].numpy(), g[f"d3{i}_src"]) and np.array_equal(out[2].numpy(), g[f"d3{i}_timestep"])
         assert np.array_equal(out[3].numpy(), g[f"d3{i}_tgt"]) and np.allclose(out[7].numpy(), g[f"d3{i}_qx"], atol=1e-12)
+
+
+def test_protein_alphabet_loaders():
+    """pretrained.py:164-205: LR_AR_* are causal, CARP_* are not; both use the 30-token PROTEIN_ALPHABET."""
+    from evodiff_amd import pretrained
+    from evodiff_amd.model import MaskedCausalConv1d, MaskedConv1d
+    model, collater, tok, scheme = pretrained.LR_AR_38M(random_init=True)
+    assert scheme == "causal-mask" and model.hparams["causal"] == 1 and model.hparams["n_tokens"] == 30
+    assert isinstance(model.embedder.layers[0].conv, MaskedCausalConv1d)
+    assert (tok.start_id, tok.stop_id, tok.pad_id, tok.mask_id) == (29, 26, 27, 28) and len(tok.alphabet) == 30
+    assert tuple(model.decoder.conv.weight.shape) == (30, 1024, 1)
+    model, collater, tok, scheme = pretrained.CARP_38M(random_init=True)
+    assert scheme == "mask" and model.hparams["causal"] == 0 and isinstance(model.embedder.layers[0].conv, MaskedConv1d)
+    np.random.seed(1)
+    src, timesteps, tgt, masks = collater([("ACDEFGHIK",)])
+    assert int((src == tok.mask_id).sum()) == int(timesteps[0]) == int(masks.sum())
+    oracle = R.build_model(dict(R.MODEL_CONFIGS["38M"], n_tokens=30, causal=True), None, None)
+    assert list(oracle.state_dict().keys()) == list(pretrained.LR_AR_38M(random_init=True)[0].state_dict().keys())

@@ -1,0 +1,39 @@
+"""Autoregressive (LR_AR_640M, causal) sampling step time: one new row per layer and step from cached convolution
+inputs (ed_ar_sample), against the reference's scheme of re-running the growing prefix (one ed_forward of length s+1
+per step, timed at a few lengths)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from evodiff_amd.pretrained import LR_AR_640M  # noqa: E402
+
+torch.manual_seed(0)
+m, _, tok, _ = LR_AR_640M(random_init=True)
+m.precision = "bf16"
+dev = torch.device("cuda", 0)
+n = 256
+wbytes = 2.0 * sum(p.numel() for p in m.parameters())
+for B in (1, 8, 64, 256):
+    uni = torch.rand((n, B), device=dev)
+    best = 1e9
+    for rep in range(3):
+        sample = torch.full((B, n + 1), tok.start_id, dtype=torch.long, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.ar_sample(sample, uni, n_steps=n)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n)
+    print(f"ed_ar_sample B={B:4d}: {best * 1e3:.3f} ms/step, {B / best:.0f} tokens/s, weights/time = "
+          f"{wbytes / best / 1e12:.2f} TB/s", flush=True)
+for L in (64, 256, 1024):
+    x = torch.randint(0, 26, (1, L), device=dev)
+    t = torch.zeros(1, dtype=torch.long, device=dev)
+    m(x, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m(x, t)
+    torch.cuda.synchronize()
+    print(f"prefix re-run, B=1 L={L}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms per forward", flush=True)
