@@ -120,6 +120,8 @@ struct ed_model {
   int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
+  int split_min_iters = 4;     // ED_OPT_SPLIT_MIN_ITERS: K-steps (of 64 channels) a workgroup keeps at least
+  bool fuse_reduce_ln = true;  // ED_OPT_FUSE_REDUCE_LN: the LayerNorm behind a split-K GEMM adds up the partial sums itself
   bool prune = true;           // ED_OPT_PRUNE
   int min_tuned_tiles = 130;   // ED_OPT_MIN_TUNED_TILES (tiles of the height the tuned kernel would use)
   std::vector<LayerPlan> plan; // per layer, for the current (B, L)
@@ -239,7 +241,11 @@ bool use_tuned_gemm(const ed_model* m, const GemmProblem& p) {
   return tiles >= m->min_tuned_tiles;
 }
 
-int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
+// `deferred`: the caller's next launch is the LayerNorm of this result.  If the K loop gets cut across workgroups the
+// reduction launch is left out and *deferred receives the problem with its partial sums (ksplit > 1) for
+// run_ln_after, which then adds them up inside the LayerNorm kernel.
+int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s, GemmProblem* deferred = nullptr) {
+  if (deferred) deferred->ksplit = 1;
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
   if (use_tuned_gemm(m, p)) {
@@ -252,7 +258,7 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
     if (p.a_bf16 && m->split_target > 0 && m->partials.p) {
       const long tiles = (long)p.B * ((p.L + 127) / 128) * ((p.N + 127) / 128);
       const int iters = p.ntaps * ((p.K + 63) / 64);
-      long ks = std::min<long>({m->split_target / tiles, (long)iters / 4, 16L});
+      long ks = std::min<long>({m->split_target / tiles, (long)iters / m->split_min_iters, 16L});
       while (ks > 1 && (size_t)ks * p.B * p.L * p.N * 4 > m->partials.bytes) --ks;
       if (ks > 1) {
         q.ksplit = (int)ks;
@@ -260,7 +266,10 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s) {
       }
     }
     LAUNCH_TRY(launch_gemm_generic(q, s));
-    if (q.ksplit > 1) LAUNCH_TRY(launch_reduce_partials(q, s));
+    if (q.ksplit > 1) {
+      if (deferred && m->fuse_reduce_ln && reduce_ln_supported(q)) *deferred = q;
+      else LAUNCH_TRY(launch_reduce_partials(q, s));
+    }
     if (kind == ED_K_CONV) kind = ED_K_CONV_OTHER;
   }
   double taps = 0;
@@ -283,6 +292,19 @@ int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, 
   LAUNCH_TRY(pr.begin());
   LAUNCH_TRY(launch_ln_act(in, in_bf16, out, out_bf16, g, b, rows, C, map, act, s));
   LAUNCH_TRY(pr.end(ED_K_LNACT, 0.0, (double)rows * C * ((in_bf16 ? 2.0 : 4.0) + (out_bf16 ? 2.0 : 4.0))));
+  return ED_OK;
+}
+
+// The LayerNorm behind a GEMM launched with `deferred` (see run_gemm): in / in_bf16 describe the GEMM's stored result,
+// which exists only if its reduction ran.
+int run_ln_after(ed_model* m, const GemmProblem& deferred, const void* in, bool in_bf16, void* out, bool out_bf16,
+                 const float* g, const float* b, int rows, int C, const LnRowMap& map, int act, hipStream_t s) {
+  if (deferred.ksplit <= 1) return run_ln(m, in, in_bf16, out, out_bf16, g, b, rows, C, map, act, s);
+  if (!out_bf16 || C != deferred.N) return fail(ED_ESTATE, "deferred split-K reduction needs a bf16 LayerNorm of the GEMM's width");
+  Probe pr(m, s);
+  LAUNCH_TRY(pr.begin());
+  LAUNCH_TRY(launch_reduce_ln(deferred, (bf16_t*)out, g, b, rows, map, act, s));
+  LAUNCH_TRY(pr.end(ED_K_LNACT, 0.0, (double)rows * C * (4.0 * deferred.ksplit + 2.0)));
   return ED_OK;
 }
 
@@ -406,9 +428,10 @@ int run_incremental_layer(ed_model* m, int k, int B, int L, int prec, hipStream_
   const LnRowMap gather_in{M_in, L, 0, 1, win_in, M_in, 0, PosBit{}};
   if ((rc = run_ln(m, x_in, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, gather_in, act, s))) return rc;
   GemmProblem g1{A, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
-  if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
+  GemmProblem dq{};
+  if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s, &dq))) return rc;
   const LnRowMap scatter_pad{M_in, M_in, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, win_in};
-  if ((rc = run_ln(m, Y, y_bf16, m->Cc[k].p, h, w.ln2_g, w.ln2_b, rows_in, H, scatter_pad, act, s))) return rc;
+  if ((rc = run_ln_after(m, dq, Y, y_bf16, m->Cc[k].p, h, w.ln2_g, w.ln2_b, rows_in, H, scatter_pad, act, s))) return rc;
   GemmProblem gc{m->Cc[k].p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
                  1, rows_out, H, H, c.kernel_size, w.dilation, h, y_bf16};
   gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
@@ -416,8 +439,8 @@ int run_incremental_layer(ed_model* m, int k, int B, int L, int prec, hipStream_
   gc.a_unbounded = true;
   gc.a_sel = win_out;
   gc.out_pitch = M_out;
-  if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
-  if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, LnRowMap::plain(rows_out), act, s))) return rc;
+  if ((rc = run_gemm(m, gc, ED_K_CONV, s, &dq))) return rc;
+  if ((rc = run_ln_after(m, dq, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, LnRowMap::plain(rows_out), act, s))) return rc;
   GemmProblem g2{A, 0, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x_out, x_in, 1, rows_out, D, H, 1, 1, h, false};
   g2.seq_rows = M_out;
   g2.a_seq_pitch = M_out;
@@ -449,6 +472,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
   // GEMM1 / conv results feed a LayerNorm straight away; in the fast path they are stored as bf16 (the
   // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
   const bool y_bf16 = h;
+  bool ln1_done = false;  // the previous block's PFF2 reduction already ran this block's first LayerNorm
   for (int i = 0; i < c.n_layers; ++i) {
     int rc;
     if (variant == STEP_INCR && i < n_inc) {
@@ -471,18 +495,20 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       x_src = m->Xc[i].as<float>();
     }
     // the 1x1 projections are row-independent: tile them over all rows as one long sequence
-    if ((rc = run_ln(m, x_src, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+    if (!ln1_done && (rc = run_ln(m, x_src, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+    ln1_done = false;
     GemmProblem g1{A, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
-    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
+    GemmProblem dq{};
+    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s, &dq))) return rc;
     long y_pitch;  // rows per sequence of the convolution result in Y
     if (pl.s_in == 1) {
       // every position: per-sequence zero halo in Cpad
       const LnRowMap to_pad{L, L, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, PosBit{}};
-      if ((rc = run_ln(m, Y, y_bf16, cpad, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
+      if ((rc = run_ln_after(m, dq, Y, y_bf16, cpad, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
       GemmProblem gc{cpad, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
                      nullptr, B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
       gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
-      if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+      if ((rc = run_gemm(m, gc, ED_K_CONV, s, &dq))) return rc;
       y_pitch = L;
     } else {
       // compact position set: neighbours at +-d are dc = d / s_in rows apart; the sequences sit back to back with
@@ -491,10 +517,10 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       const long gap = (long)half * dc, pitch = M_in + gap;
       char* Cc = (char*)m->Cprune.p + (size_t)pl.cp_row * H * esz;
       const LnRowMap to_compact{M_in, M_in, 0, 1, PosBit{}, pitch, gap, PosBit{}};
-      if ((rc = run_ln(m, Y, y_bf16, Cc, h, w.ln2_g, w.ln2_b, rows_in, H, to_compact, act, s))) return rc;
+      if ((rc = run_ln_after(m, dq, Y, y_bf16, Cc, h, w.ln2_g, w.ln2_b, rows_in, H, to_compact, act, s))) return rc;
       GemmProblem gc{Cc, 0, gap, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
                      1, (int)(B * pitch - gap), H, H, c.kernel_size, dc, h, y_bf16};
-      if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
+      if ((rc = run_gemm(m, gc, ED_K_CONV, s, &dq))) return rc;
       y_pitch = pitch;
     }
     // positions kept for the next layer: every in_mul-th row, starting at the row the fill position selects
@@ -506,7 +532,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       sel.mask = in_mul - 1;
     }
     const LnRowMap keep{M_out, y_pitch, 0, in_mul, sel, M_out, 0, PosBit{}};
-    if ((rc = run_ln(m, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, keep, act, s))) return rc;
+    if ((rc = run_ln_after(m, dq, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, keep, act, s))) return rc;
     GemmProblem g2{A, rows_out, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x_dst, x_src, 1, rows_out, D, H, 1, 1, h, false};
     if (in_mul > 1) {
       g2.out = Xo;
@@ -514,7 +540,15 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       g2.resid_sel = sel;
       std::swap(Xc, Xo);
     }
-    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s))) return rc;
+    // a split-K PFF2 leaves its reduction to the first LayerNorm of the next block (which also stores the new residual
+    // stream): that LayerNorm reads exactly the rows this block produced
+    GemmProblem dq2{};
+    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s, h && i + 1 < c.n_layers ? &dq2 : nullptr))) return rc;
+    if (dq2.ksplit > 1) {
+      const LayerW& wn = m->layers[i + 1];
+      if ((rc = run_ln_after(m, dq2, nullptr, false, A, h, wn.ln1_g, wn.ln1_b, rows_out, D, LnRowMap::plain(rows_out), act, s))) return rc;
+      ln1_done = true;
+    }
     if (acts)
       HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows_out * D, Xc, (size_t)rows_out * D * 4, hipMemcpyDeviceToDevice, s));
   }
@@ -567,6 +601,7 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   void* A = m->Abuf.p;
   void* Y = m->Ybuf.p;
   int rc;
+  bool ln1_done = false;
   {
     Probe pr(m, s);
     LAUNCH_TRY(pr.begin());
@@ -576,11 +611,13 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   }
   for (int k = 0; k < c.n_layers; ++k) {
     const LayerW& w = m->layers[k];
-    if ((rc = run_ln(m, x, false, A, h, w.ln1_g, w.ln1_b, B, D, LnRowMap::plain(B), act, s))) return rc;
+    if (!ln1_done && (rc = run_ln(m, x, false, A, h, w.ln1_g, w.ln1_b, B, D, LnRowMap::plain(B), act, s))) return rc;
+    ln1_done = false;
     GemmProblem g1{A, B, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, B, H, D, 1, 1, h, h};
-    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s))) return rc;
+    GemmProblem dq{};
+    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s, &dq))) return rc;
     const LnRowMap to_cache{1, 1, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, pos};
-    if ((rc = run_ln(m, Y, h, m->Car[k].p, h, w.ln2_g, w.ln2_b, B, H, to_cache, act, s))) return rc;
+    if ((rc = run_ln_after(m, dq, Y, h, m->Car[k].p, h, w.ln2_g, w.ln2_b, B, H, to_cache, act, s))) return rc;
     GemmProblem gc{m->Car[k].p, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
                    nullptr, 1, B, H, H, c.kernel_size, w.dilation, h, h};
     gc.tap_center = c.kernel_size - 1;
@@ -588,10 +625,16 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
     gc.a_unbounded = true;   // rows p - tau*d >= -halo: real zero padding in front of every sequence
     gc.a_sel = pos;
     gc.out_pitch = 1;
-    if ((rc = run_gemm(m, gc, ED_K_CONV, s))) return rc;
-    if ((rc = run_ln(m, Y, h, A, h, w.ln3_g, w.ln3_b, B, H, LnRowMap::plain(B), act, s))) return rc;
+    if ((rc = run_gemm(m, gc, ED_K_CONV, s, &dq))) return rc;
+    if ((rc = run_ln_after(m, dq, Y, h, A, h, w.ln3_g, w.ln3_b, B, H, LnRowMap::plain(B), act, s))) return rc;
     GemmProblem g2{A, B, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x, x, 1, B, D, H, 1, 1, h, false};
-    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s))) return rc;
+    GemmProblem dq2{};
+    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s, h && k + 1 < c.n_layers ? &dq2 : nullptr))) return rc;
+    if (dq2.ksplit > 1) {
+      const LayerW& wn = m->layers[k + 1];
+      if ((rc = run_ln_after(m, dq2, nullptr, false, A, h, wn.ln1_g, wn.ln1_b, B, D, LnRowMap::plain(B), act, s))) return rc;
+      ln1_done = true;
+    }
   }
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
@@ -1109,6 +1152,14 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_MIN_TUNED_TILES:
       if (value < 0) return fail(ED_EINVAL, "ED_OPT_MIN_TUNED_TILES must be >= 0");
       m->min_tuned_tiles = value;
+      break;
+    case ED_OPT_FUSE_REDUCE_LN:
+      if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_REDUCE_LN takes 0 or 1");
+      m->fuse_reduce_ln = value != 0;
+      break;
+    case ED_OPT_SPLIT_MIN_ITERS:
+      if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");
+      m->split_min_iters = value;
       break;
     default:
       return fail(ED_EINVAL, "unknown option %d", option);

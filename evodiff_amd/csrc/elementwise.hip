@@ -362,6 +362,87 @@ __global__ __launch_bounds__(256) void ln_act_fast_kernel(const void* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Split-K reduction + LayerNorm + activation in one launch (small problems of the fast path).  A GEMM whose K loop
+// was cut across workgroups leaves ksplit raw partial sums per output element; the LayerNorm that consumes its result
+// adds them up itself (in the fixed order z = 0, 1, ..., plus the bias, rounded to bf16 when the GEMM's result would
+// have been stored as bf16), so the reduction launch and the round trip of the result through memory disappear.
+// One WORKGROUP per row, one 16-byte piece per thread: the ksplit loads of a thread are independent and in flight
+// together (a wave-per-row form of this kernel reads ksplit x 5 KB serially per wave and lost to the two launches).
+// With a residual (PFF2 of a block followed by the first LayerNorm of the next block) the reduced fp32 row is also
+// stored: it is the residual stream.
+// ---------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(1024) void reduce_ln_kernel(const float* __restrict__ partial, long pstride, int ksplit,
+                                                         const float* __restrict__ bias, int round_bf16,
+                                                         const float* resid, int resid_mul, PosBit resid_sel,
+                                                         float* xout, bf16_t* __restrict__ out,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int C, LnRowMap map) {
+  __shared__ float red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (int)blockDim.x >> 6;
+  const unsigned row = blockIdx.x, rps = (unsigned)map.rows_per_seq;
+  const unsigned seq = row / rps, m = row - seq * rps;
+  const long irow = map.in_row0 + (long)seq * map.in_pitch + (long)m * map.in_mul + map.in_sel.get();
+  const long orow = map.out_row0 + (long)seq * map.out_pitch + m + map.out_sel.get();
+  const int idx = tid * 4;
+  const bool on = idx < C;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) {
+    const float* p = partial + irow * C + idx;
+#pragma unroll 8
+    for (int z = 0; z < ksplit; ++z) {
+      const float4 x = *(const float4*)(p + z * pstride);
+      t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+    }
+    float4 b = *(const float4*)(bias + idx);
+    if (resid) {  // PFF2: the reduced value is the new residual stream (fp32, stored) AND this LayerNorm's input
+      const float4 x = *(const float4*)(resid + (irow * resid_mul + resid_sel.get()) * C + idx);
+      b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
+    }
+    t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    if (xout) *(float4*)(xout + irow * C + idx) = t;
+    if (round_bf16) {
+      t.x = bf16_bits_to_f32(f32_to_bf16_bits(t.x)); t.y = bf16_bits_to_f32(f32_to_bf16_bits(t.y));
+      t.z = bf16_bits_to_f32(f32_to_bf16_bits(t.z)); t.w = bf16_bits_to_f32(f32_to_bf16_bits(t.w));
+    }
+  }
+  float s = (t.x + t.y) + (t.z + t.w);
+  float q = fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w)));
+  s = wave_sum_dpp(s);
+  q = wave_sum_dpp(q);
+  if (lane == 0) {
+    red[0][wid] = s;
+    red[1][wid] = q;
+  }
+  __syncthreads();
+  s = 0.f;
+  q = 0.f;
+  for (int w = 0; w < nw; ++w) {
+    s += red[0][w];
+    q += red[1][w];
+  }
+  if (!on) return;
+  const float inv = 1.0f / (float)C;
+  const float mean = s * inv;
+  const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * inv), 0.f) + LN_EPS);
+  const float shift = -mean * rstd;
+  const float4 gm = *(const float4*)(gamma + idx);
+  const float4 bt = *(const float4*)(beta + idx);
+  f32x2 y0 = {fmaf(fmaf(t.x, rstd, shift), gm.x, bt.x), fmaf(fmaf(t.y, rstd, shift), gm.y, bt.y)};
+  f32x2 y1 = {fmaf(fmaf(t.z, rstd, shift), gm.z, bt.z), fmaf(fmaf(t.w, rstd, shift), gm.w, bt.w)};
+  if constexpr (ACT == 1) {
+    y0 = gelu_sigmoid_fit2(y0);
+    y1 = gelu_sigmoid_fit2(y1);
+  } else if constexpr (ACT == 2) {
+    y0 = __builtin_elementwise_max(y0, (f32x2)(0.f));
+    y1 = __builtin_elementwise_max(y1, (f32x2)(0.f));
+  }
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 pk = {(__bf16)y0.x, (__bf16)y0.y, (__bf16)y1.x, (__bf16)y1.y};
+  *(bf16x4*)(out + orow * C + idx) = pk;
+}
+
 // last_norm + decoder for one row held by one wave: returns logit k in lane k (k < n_out <= 64).
 template <int NCH>
 __device__ __forceinline__ float row_logits(const float* X, long row, int D, int lane, const float* gamma,
@@ -634,6 +715,30 @@ hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16,
                        C, map, act)
   ED_NCH_DISPATCH(C, ED_CALL);
 #undef ED_CALL
+  return hipGetLastError();
+}
+
+bool reduce_ln_supported(const GemmProblem& q) {
+  // the GEMM's output rows must be its flat rows (the LayerNorm's input map then indexes the partial sums directly)
+  const bool plain_out = q.seq_rows == 0 || (q.out_pitch == q.seq_rows && q.out_sel.order == nullptr);
+  if (q.resid && (q.seq_rows != 0 || q.out_bf16)) return false;
+  return q.ksplit > 1 && q.partial && plain_out && q.N % 4 == 0 && q.N <= 4096;
+}
+
+hipError_t launch_reduce_ln(const GemmProblem& q, bf16_t* out, const float* gamma, const float* beta, int rows,
+                            const LnRowMap& map, int act, hipStream_t stream) {
+  if (!reduce_ln_supported(q) || rows <= 0 || act < 0 || act > 2) return hipErrorInvalidValue;
+  const int C = q.N;
+  const dim3 grid((unsigned)rows), block((unsigned)(((C / 4) + 63) / 64 * 64));
+  const long pstride = (long)q.B * q.L * q.N;
+#define ED_RL(AC)                                                                                                 \
+  hipLaunchKernelGGL((reduce_ln_kernel<AC>), grid, block, 0, stream, (const float*)q.partial, pstride, q.ksplit,  \
+                     q.bias, q.out_bf16 ? 1 : 0, q.resid, q.resid_mul, q.resid_sel, q.resid ? (float*)q.out : nullptr, \
+                     out, gamma, beta, C, map)
+  if (act == 0) ED_RL(0);
+  else if (act == 1) ED_RL(1);
+  else ED_RL(2);
+#undef ED_RL
   return hipGetLastError();
 }
 

@@ -133,6 +133,13 @@ struct LnRowMap {
 hipError_t launch_ln_act(const void* in, bool in_bf16, void* out, bool out_bf16, const float* gamma,
                          const float* beta, int rows, int C, const LnRowMap& map, int act, hipStream_t stream);
 
+// The same LayerNorm (bf16 out) reading the result of a split-K GEMM `q` straight from its partial sums (q.partial,
+// q.ksplit; launch_reduce_partials is then NOT run): in = bias + sum_z partial[z], rounded to bf16 if q.out_bf16.
+// The map's input rows index q's flat output rows.
+bool reduce_ln_supported(const GemmProblem& q);
+hipError_t launch_reduce_ln(const GemmProblem& q, bf16_t* out, const float* gamma, const float* beta, int rows,
+                            const LnRowMap& map, int act, hipStream_t stream);
+
 // logits[r][k] = dec_b[k] + dec_w[k] . LayerNorm(X[r])  for all rows (ByteNetLMTime.forward tail).
 hipError_t launch_final_nll(const float* X, const float* gamma, const float* beta, const float* dec_w,
                             const float* dec_b, const int64_t* targets, const uint8_t* select, float* nll, int rows,

@@ -295,6 +295,33 @@ def test_incremental_layers_change_nothing(dev, cfg, B, L):
             assert np.abs(p0[-1][same] - p1[-1][same]).max() < 5e-2
 
 
+@pytest.mark.parametrize("cfg,B,L", [(BIG640, 2, 100), (BIG512, 3, 256), (MID, 1, 37)])
+def test_fused_split_k_layernorm_matches_separate_reduction(dev, cfg, B, L):
+    """ED_OPT_FUSE_REDUCE_LN: the LayerNorm behind a split-K GEMM adds up the partial sums itself.  Same additions in
+    the same order ahead of the statistics, so against the separate reduction launch only the order of the row sums
+    differs: logits and softmax rows agree far inside the bf16 tolerance, and both stay within it of the oracle."""
+    oracle = R.build_model(cfg, None, 41)
+    m = product_model(oracle, cfg, precision="bf16")
+    rng = np.random.default_rng(B * L)
+    x = torch.from_numpy(rng.integers(0, 26, (B, L)))
+    x[:, rng.permutation(L)[: L // 3]] = R.MASK_ID
+    zeros = torch.zeros(B, dtype=torch.long)
+    want = oracle(x, zeros).detach().numpy()
+    n = min(L, 6)
+    order = torch.from_numpy(rng.permutation(L)[:n].astype(np.int32))
+    uni = torch.from_numpy(rng.random((n, B), dtype=np.float32)).to(dev)
+    logits, probs = [], []
+    for fuse in (1, 0):
+        m.set_option("fuse_reduce_ln", fuse)
+        logits.append(m(x.to(dev), zeros.to(dev)).cpu().numpy())
+        m.use_graph = False
+        sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+        probs.append(m.oadm_sample(sample, order, uni, R.OADM_DRAW, return_probs=True).cpu().numpy())
+        assert rel_err(logits[-1], want) < BF16_TOL
+    assert rel_err(logits[0], logits[1]) < 4e-3
+    assert np.abs(probs[0][0] - probs[1][0]).max() < 4e-3
+
+
 def test_640m_steps_vs_oracle(dev):
     """OA_DM_640M geometry (config 2 at reduced batch): 8 teacher-forced steps, fp32 1e-4 and bf16."""
     cfg = R.MODEL_CONFIGS["640M"]
