@@ -1107,7 +1107,7 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   GemmProblem p{A_dev, (long)a_seq_pitch, (long)a_row0, W_dev, bias_dev, out_dev, resid_dev, B, L, N, K, ntaps,
                 dilation, a_bf16 != 0, out_bf16 != 0};
   hipStream_t s = (hipStream_t)stream;
-  if (kernel >= 3) {  // diagnostic ablations of the tuned kernel (3: no MFMAs, 4: no DMA); results are not valid
+  if (kernel >= 3 && kernel < 100) {  // diagnostic ablations of the tuned kernel (3: no MFMAs, 4: no DMA); results are not valid
     p.ablate = kernel - 2;
     kernel = 2;
     if (p.ablate == 7) {  // in-kernel clock stamps: four values per 256-row tile
@@ -1116,7 +1116,17 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
       p.stamps = g_stamp_buf;
     }
   }
-  if (kernel == 2 || (kernel == 0 && gemm_bf16_supported(p))) {
+  if (kernel >= 100) {  // small-tile kernel with its K loop cut kernel - 100 ways + the reduction (bf16 only); stamps if set
+    static DevBuf dbg_partials;
+    p.ksplit = kernel - 100;
+    if (!p.a_bf16 || p.ksplit < 1 || p.ksplit > 16) return fail(ED_EINVAL, "kernel 100 + ksplit: bf16, ksplit in [1, 16]");
+    HIP_TRY(dbg_partials.ensure((size_t)p.ksplit * B * L * N * 4));
+    p.partial = dbg_partials.as<float>();
+    const int64_t wgs = (int64_t)((N + 127) / 128) * B * ((L + 127) / 128) * p.ksplit;
+    if (g_stamp_buf && g_stamp_cap >= 4 * wgs) p.stamps = g_stamp_buf;
+    LAUNCH_TRY(launch_gemm_generic(p, s));
+    if (p.ksplit > 1) LAUNCH_TRY(launch_reduce_partials(p, s));
+  } else if (kernel == 2 || (kernel == 0 && gemm_bf16_supported(p))) {
     if (!gemm_bf16_supported(p)) return fail(ED_EINVAL, "shape outside the tuned bf16 kernel's contract");
     LAUNCH_TRY(launch_gemm_bf16(p, s));
   } else {

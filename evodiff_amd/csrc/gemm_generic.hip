@@ -34,6 +34,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
+  // diagnostics (GemmProblem::stamps): 100-MHz ticks at entry, after the first K-step's operands are in LDS, after the
+  // K loop and at the end, per workgroup
+  long long* const stamp = g.stamps ? g.stamps + 4 * ((long)blockIdx.x + gridDim.x * ((long)blockIdx.y + gridDim.y * (long)blockIdx.z)) : nullptr;
+  if (stamp && tid == 0) stamp[0] = (long long)__builtin_amdgcn_s_memrealtime();
   const int tiles_per_seq = (g.L + BM - 1) / BM;
   const int b = blockIdx.y / tiles_per_seq;
   const int l0 = (blockIdx.y % tiles_per_seq) * BM;
@@ -71,19 +75,29 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   // PF register sets: the loads of K-step it+PF are issued as soon as the set of step it has been written to LDS, so
   // every load has PF full steps to return (small problems run few workgroups per CU, stream cold weights from HBM
   // and are latency-bound otherwise).
+  // gload() is called for it_begin, it_begin + 1, ... in this order, so the (tap, slice) pair and the two row
+  // pointers are carried along instead of being recomputed (a division and 64-bit products per call made the
+  // prologue of a small problem as long as its K loop).
   constexpr int PF = 4;
   uint4 ra[PF][4], rb[PF][4];
-  auto gload = [&](int it, uint4 (&a4)[4], uint4 (&b4)[4]) {
-    const int tap = it / ksteps;
-    const int ks = it - tap * ksteps;
+  int g_tap = it_begin / ksteps, g_ks = it_begin - g_tap * ksteps;
+  const char *a_tap = nullptr, *w_tap = nullptr;  // this thread's A / W row of the current tap, at its 64-byte half
+  bool row_on = false;
+  auto set_tap = [&](int tap) {
     const int shift = (tap - half_taps) * g.dilation;
     const int l = l0 + lrow + shift;
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    const bool k_on = !(last_half_empty && ks == ksteps - 1 && lhalf == 1);
-    const bool row_on = g.seq_rows > 0 ? (l0 + lrow < g.L && (g.a_unbounded || (l >= 0 && l < g.L))) : (l >= 0 && l < g.L);
+    row_on = g.seq_rows > 0 ? (l0 + lrow < g.L && (g.a_unbounded || (l >= 0 && l < g.L))) : (l >= 0 && l < g.L);
     const long a_row = g.seq_rows > 0 ? a_row_grouped + shift : (long)b * g.a_seq_pitch + g.a_row0 + l;
+    a_tap = Abase + a_row * g.K * ESZ + lhalf * 64;
+    w_tap = Wbase + ((long)tap * g.N + nrow) * g.K * ESZ + lhalf * 64;
+  };
+  set_tap(g_tap);
+  auto gload = [&](uint4 (&a4)[4], uint4 (&b4)[4]) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const bool k_on = !(last_half_empty && g_ks == ksteps - 1 && lhalf == 1);
+    const int koff = g_ks * ROW_BYTES;
     if (k_on && row_on) {
-      const uint4* p = (const uint4*)(Abase + (a_row * g.K + (long)ks * KSTEP) * ESZ + lhalf * 64);
+      const uint4* p = (const uint4*)(a_tap + koff);
 #pragma unroll
       for (int i = 0; i < 4; ++i) a4[i] = p[i];
     } else {
@@ -91,12 +105,16 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       for (int i = 0; i < 4; ++i) a4[i] = z;
     }
     if (k_on && nrow < g.N) {
-      const uint4* p = (const uint4*)(Wbase + (((long)tap * g.N + nrow) * g.K + (long)ks * KSTEP) * ESZ + lhalf * 64);
+      const uint4* p = (const uint4*)(w_tap + koff);
 #pragma unroll
       for (int i = 0; i < 4; ++i) b4[i] = p[i];
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) b4[i] = z;
+    }
+    if (++g_ks == ksteps) {
+      g_ks = 0;
+      set_tap(++g_tap);
     }
   };
 
@@ -116,7 +134,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = b4[i];
     }
     __syncthreads();
-    if (it + PF < it_end) gload(it + PF, a4, b4);
+    if (stamp && tid == 0 && it == it_begin) stamp[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (it + PF < it_end) gload(a4, b4);
     // Each lane takes 32 contiguous bytes of its row at byte 64*h + 32*fh of the slice.  The k order seen by the
     // MFMA is a permutation of the true k, identical for A and B, so the sum over k is unchanged.
 #pragma unroll
@@ -157,32 +176,66 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
 
 #pragma unroll
   for (int u = 0; u < PF; ++u)
-    if (it_begin + u < it_end) gload(it_begin + u, ra[u], rb[u]);
+    if (it_begin + u < it_end) gload(ra[u], rb[u]);
   for (int it = it_begin; it < it_end; it += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u)
       if (it + u < it_end) step(it + u, ra[u], rb[u]);
   }
 
+  if (stamp && tid == 0) stamp[2] = (long long)__builtin_amdgcn_s_memrealtime();
+  // Element (i, j, r) of this lane sits at tile row 32 i + (r & 3) + 8 (r >> 2) + 4 fh, tile column 32 j + fr: the lane
+  // part of the offset is computed once, the rest are compile-time multiples of N (32-bit: a tile spans 128 rows).
+  const int row_w = l0 + wr * 64, col_w = n0 + wc * 64;            // first row / column of this wave's 64 x 64 piece
+  const int lane_off = 4 * fh * g.N + fr;
+  const int row_lim = g.L - row_w - 4 * fh;                         // rows 32 i + c(r) below this exist
   if (g.ksplit > 1) {  // raw partial sums; bias, residual and rounding happen in the reduction
-    float* part = g.partial + (long)blockIdx.z * g.B * g.L * g.N;
+    float* part = g.partial + ((long)blockIdx.z * g.B * g.L + (long)b * g.L + row_w) * g.N + col_w;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + fr;
-        if (n >= g.N) continue;
+        if (col_w + j * 32 + fr >= g.N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          if (l < g.L) part[((long)b * g.L + l) * g.N + n] = acc[i][j][r];
+          const int tr = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (tr < row_lim) part[lane_off + tr * g.N + j * 32] = acc[i][j][r];
+        }
+      }
+    if (stamp) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 0) stamp[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
+  const int rsel = RESID ? g.resid_sel.get() : 0;
+  if (g.seq_rows == 0) {
+    // epilogue: C[row][col] with col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const long orow = (long)b * g.L + row_w;
+    char* const obase = (char*)g.out + (orow * g.N + col_w) * (OUT_BF16 ? 2 : 4);
+    const float* const rbase = RESID ? g.resid + ((orow * g.resid_mul + rsel) * g.N + col_w) : nullptr;
+    const int lane_roff = 4 * fh * g.resid_mul * g.N + fr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (col_w + j * 32 + fr >= g.N) continue;
+        const float bias = g.bias[col_w + j * 32 + fr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tr = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (tr >= row_lim) continue;
+          const int o = lane_off + tr * g.N + j * 32;
+          float v = acc[i][j][r] + bias;
+          if constexpr (RESID) v += rbase[lane_roff + tr * g.resid_mul * g.N + j * 32];
+          if constexpr (OUT_BF16) ((bf16_t*)obase)[o] = f32_to_bf16_bits(v);
+          else ((float*)obase)[o] = v;
         }
       }
     return;
   }
-  const int rsel = RESID ? g.resid_sel.get() : 0;
-  const int osel = g.seq_rows > 0 ? g.out_sel.get() : 0;
-  // epilogue: C[row][col] with col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // row groups: output and residual rows addressed per sequence
+  const int osel = g.out_sel.get();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -194,13 +247,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       for (int r = 0; r < 16; ++r) {
         const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (l >= g.L) continue;
-        long o = ((long)b * g.L + l) * g.N + n;
-        long ro = (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + n;
-        if (g.seq_rows > 0) {
-          const unsigned bs = (unsigned)l / (unsigned)g.seq_rows, ls = (unsigned)l - bs * (unsigned)g.seq_rows;
-          o = ((long)bs * g.out_pitch + osel + ls) * g.N + n;
-          ro = ((long)bs * g.resid_pitch + (long)ls * g.resid_mul + rsel) * g.N + n;
-        }
+        const unsigned bs = (unsigned)l / (unsigned)g.seq_rows, ls = (unsigned)l - bs * (unsigned)g.seq_rows;
+        const long o = ((long)bs * g.out_pitch + osel + ls) * g.N + n;
+        const long ro = ((long)bs * g.resid_pitch + (long)ls * g.resid_mul + rsel) * g.N + n;
         float v = acc[i][j][r] + bias;
         if constexpr (RESID) v += g.resid[ro];
         if constexpr (OUT_BF16) ((bf16_t*)g.out)[o] = f32_to_bf16_bits(v);

@@ -44,7 +44,11 @@ def main():
                                      a.out_bf16, a.kernel, stream))
 
     stamps = None
-    if a.kernel == 9:
+    if a.kernel >= 100:
+        wgs = ((a.N + 127) // 128) * B * ((L + 127) // 128) * (a.kernel - 100)
+        stamps = torch.zeros(4 * wgs, dtype=torch.int64, device=dev)
+        _lib.check(lib.ed_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()))
+    elif a.kernel == 9:
         stamps = torch.zeros(4 * B * ((L + 255) // 256) * ((a.N + 255) // 256), dtype=torch.int64, device=dev)
         _lib.check(lib.ed_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()))
     for _ in range(5):
@@ -61,7 +65,14 @@ def main():
     flops = 2.0 * B * rows * a.N * a.K
     print(f"B={B} L={L} N={a.N} K={a.K} taps={a.taps} dil={a.dil} kernel={a.kernel}: {ms * 1e3:.1f} us/launch, "
           f"{flops / ms / 1e9:.1f} TFLOP/s (in-range taps)")
-    if stamps is not None:
+    if stamps is not None and a.kernel >= 100:
+        st = stamps.view(-1, 4).cpu().double() / 100.0     # us; the last launch's values
+        t0 = st[:, 0].min()
+        q = lambda v: f"{v.min().item():.2f}/{v.median().item():.2f}/{v.max().item():.2f}"
+        print(f"stamps over {len(st)} workgroups (us after the first workgroup's entry, min/median/max): entry {q(st[:, 0] - t0)}, "
+              f"first operands in LDS {q(st[:, 1] - t0)}, K loop done {q(st[:, 2] - t0)}, stores done {q(st[:, 3] - t0)}")
+        _lib.check(lib.ed_debug_set_stamp_buffer(None, 0))
+    elif stamps is not None:
         st = stamps.view(-1, 4).cpu().double()
         st = st[st[:, 3] > 0]
         clk = (st[:, :3].sum(1) / st[:, 3]).median().item() * 100.0
