@@ -120,6 +120,7 @@ struct ed_model {
   int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
+  int partials_mb = 32;        // ED_OPT_PARTIALS_MB: size of that workspace (a cut needs ksplit x rows x N x 4 bytes)
   int split_min_iters = 4;     // ED_OPT_SPLIT_MIN_ITERS: K-steps (of 64 channels) a workgroup keeps at least
   bool fuse_reduce_ln = true;  // ED_OPT_FUSE_REDUCE_LN: the LayerNorm behind a split-K GEMM adds up the partial sums itself
   bool prune = true;           // ED_OPT_PRUNE
@@ -369,7 +370,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   HIP_TRY(need(m->Cprune, pbytes));
   if (prelayout && m->Cprune.p) HIP_TRY(hipMemsetAsync(m->Cprune.p, 0, m->Cprune.bytes, s));
   if (m->plan_s_final > 1) HIP_TRY(need(m->X2, ((size_t)B * L / 2 + 256) * c.d_model * 4));
-  HIP_TRY(need(m->partials, (size_t)32 << 20));
+  HIP_TRY(need(m->partials, (size_t)m->partials_mb << 20));
   // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
   m->n_inc = 0;
   if (m->incremental && c.timesteps == 0 && !c.causal) {
@@ -1166,6 +1167,11 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_FUSE_REDUCE_LN:
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_REDUCE_LN takes 0 or 1");
       m->fuse_reduce_ln = value != 0;
+      break;
+    case ED_OPT_PARTIALS_MB:
+      if (value < 1 || value > 4096) return fail(ED_EINVAL, "ED_OPT_PARTIALS_MB must be in [1, 4096]");
+      m->partials_mb = value;
+      m->ws_B = m->ws_L = 0;
       break;
     case ED_OPT_SPLIT_MIN_ITERS:
       if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");

@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().ed_abi_version() == 1
 
 
+def test_python_option_names_match_the_header_enum():
+    """evodiff_amd._lib.OPTIONS mirrors `enum { ED_OPT_* }` of include/evodiff_hip.h value for value."""
+    from evodiff_amd import _lib
+    header = open(os.path.join(ROOT, "include", "evodiff_hip.h")).read()
+    enum = re.search(r"enum\s*\{\s*(ED_OPT_[^}]*)\}", header).group(1)
+    declared = {name[len("ED_OPT_"):].lower(): int(value) for name, value in re.findall(r"(ED_OPT_[A-Z_]+)\s*=\s*(\d+)", enum)}
+    assert declared == _lib.OPTIONS
+    for name in declared:                       # every option is documented in the header's comment block
+        assert "ED_OPT_" + name.upper() + " (default" in header, name
+
+
 def test_argument_validation_without_a_gpu():
     """Pure host-side rejections (no HIP call is reached)."""
     from evodiff_amd import _lib
