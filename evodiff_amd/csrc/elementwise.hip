@@ -534,21 +534,71 @@ __global__ __launch_bounds__(256) void final_nll_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// OA-DM tail: generate.py:198-211.  One wave per sequence; only row order[step] is decoded.
+// OA-DM tail: generate.py:198-211.  One workgroup per sequence; only row order[step] is decoded (the logits spread over
+// its waves, softmax and draw on the first).
 // ---------------------------------------------------------------------------------------------------
+// The same logits spread over the OADM_WAVES waves of a workgroup: every wave normalises the row itself (the loads hit
+// the same lines) and takes the outputs k = wave, wave + OADM_WAVES, ... - at most four, so their weight loads are all
+// in flight together; each dot product runs exactly as in row_logits.  Results go to `out[k]` (LDS).
+constexpr int OADM_WAVES = 8;
 template <int NCH>
-__global__ __launch_bounds__(64) void final_oadm_kernel(const float* __restrict__ X, const float* gamma,
+__device__ __forceinline__ void row_logits_spread(const float* X, long row, int D, int lane, int wave,
+                                                  const float* gamma, const float* beta, const float* dec_w,
+                                                  const float* dec_b, int n_out, float* out) {
+  float v[NCH][4];
+  load_row<NCH, false>(X, row, D, lane, v);
+  normalize_row<NCH>(v, D, lane);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = (c * 64 + lane) * 4;
+    if (idx < D) {
+      const float4 gm = *(const float4*)(gamma + idx);
+      const float4 bt = *(const float4*)(beta + idx);
+      v[c][0] = fmaf(v[c][0], gm.x, bt.x); v[c][1] = fmaf(v[c][1], gm.y, bt.y);
+      v[c][2] = fmaf(v[c][2], gm.z, bt.z); v[c][3] = fmaf(v[c][3], gm.w, bt.w);
+    }
+  }
+  for (int k0 = wave; k0 < n_out; k0 += 4 * OADM_WAVES) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k0 + u * OADM_WAVES, k = kk < n_out ? kk : n_out - 1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int idx = (c * 64 + lane) * 4;
+        if (idx < D) {
+          const float4 w = *(const float4*)(dec_w + (long)k * D + idx);
+          s[u] = fmaf(v[c][0], w.x, s[u]); s[u] = fmaf(v[c][1], w.y, s[u]);
+          s[u] = fmaf(v[c][2], w.z, s[u]); s[u] = fmaf(v[c][3], w.w, s[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k0 + u * OADM_WAVES;
+      const float t = wave_sum_dpp(s[u]);
+      if (kk < n_out && lane == 0) out[kk] = t + dec_b[kk];
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64 * OADM_WAVES) void final_oadm_kernel(const float* __restrict__ X, const float* gamma,
                                                         const float* beta, const float* dec_w, const float* dec_b,
                                                         int64_t* tokens, const int* __restrict__ order,
                                                         const float* __restrict__ uniforms, const StepState* state,
                                                         float* probs, int B, int L, int D, int n_draw,
                                                         int x_rows_per_seq, int x_shift, int write_shift) {
-  const int lane = threadIdx.x, b = blockIdx.x;
+  __shared__ float logits[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
   const int step = state->step;
   const int pos = order[step];
   const long row = (long)b * L + pos;
   const long xrow = (long)b * x_rows_per_seq + (pos >> x_shift);
-  const float logit = row_logits<NCH>(X, xrow, D, lane, gamma, beta, dec_w, dec_b, n_draw);
+  row_logits_spread<NCH>(X, xrow, D, lane, wave, gamma, beta, dec_w, dec_b, n_draw, logits);
+  __syncthreads();
+  if (wave != 0) return;
+  const float logit = lane < n_draw ? logits[lane] : 0.f;
   const float p = lane_softmax(logit, lane, n_draw);
   if (probs != nullptr && lane < n_draw) probs[((long)step * B + b) * n_draw + lane] = p;
   // inverse CDF: index = #{k : cdf[k] <= u * cdf[n-1]}, cdf = left-to-right fp32 running sum
@@ -772,7 +822,7 @@ hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, co
                              const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
                              int n_draw, hipStream_t stream, int write_shift) {
   if (D % 4 != 0 || n_draw > 64 || n_draw < 1 || B <= 0) return hipErrorInvalidValue;
-  const dim3 grid(B), block(64);
+  const dim3 grid(B), block(64 * OADM_WAVES);
 #define ED_CALL(N)                                                                                             \
   hipLaunchKernelGGL((final_oadm_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, tokens, order, \
                      uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift, write_shift)

@@ -7,7 +7,8 @@
 // zero ('same' padding) and taps whose whole 128-row tile is outside are skipped.
 //
 // This is the correctness-first kernel: 128x128 output tile per 256-thread workgroup (4 waves, each
-// 64x64 as 2x2 MFMA 32x32 tiles), register-staged global->LDS copies (two K-steps ahead) with bounds checks, so
+// 64x64 as 2x2 MFMA 32x32 tiles), register-staged global->LDS copies (four K-steps ahead, two LDS stages, one barrier
+// per step) with bounds checks, so
 // it takes any B, L, N and any K that is a multiple of 64 bytes.  It is the fp32 validation path
 // (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) and the fallback for bf16 shapes the tuned kernel
 // in gemm_bf16.hip does not cover.
@@ -28,9 +29,8 @@ template <bool BF16, bool OUT_BF16, bool RESID>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int KSTEP = ROW_BYTES / ESZ;
-  __shared__ __attribute__((aligned(16))) char lds[2 * BM * LDS_STRIDE];
-  char* ldsA = lds;
-  char* ldsB = lds + BM * LDS_STRIDE;
+  constexpr int TILE = BM * LDS_STRIDE, STAGE = 2 * TILE;  // A tile + W tile of one K-step
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];  // two stages: step it+1 is written while step it is read
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -75,15 +75,16 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   // PF register sets: the loads of K-step it+PF are issued as soon as the set of step it has been written to LDS, so
   // every load has PF full steps to return (small problems run few workgroups per CU, stream cold weights from HBM
   // and are latency-bound otherwise).
-  // gload() is called for it_begin, it_begin + 1, ... in this order, so the (tap, slice) pair and the two row
-  // pointers are carried along instead of being recomputed (a division and 64-bit products per call made the
-  // prologue of a small problem as long as its K loop).
+  // gload() is called for it_begin, it_begin + 1, ... in this order, so the (tap, slice) pair and the two row pointers
+  // are carried along instead of being recomputed (a division and 64-bit products per call made the prologue of a
+  // small problem as long as its K loop).
   constexpr int PF = 4;
+  static_assert(PF % 2 == 0, "the LDS stage of a step is the parity of its register set");
   uint4 ra[PF][4], rb[PF][4];
   int g_tap = it_begin / ksteps, g_ks = it_begin - g_tap * ksteps;
   const char *a_tap = nullptr, *w_tap = nullptr;  // this thread's A / W row of the current tap, at its 64-byte half
   bool row_on = false;
-  auto set_tap = [&](int tap) {
+  auto set_tap = [&](int tap) __attribute__((always_inline)) {
     const int shift = (tap - half_taps) * g.dilation;
     const int l = l0 + lrow + shift;
     row_on = g.seq_rows > 0 ? (l0 + lrow < g.L && (g.a_unbounded || (l >= 0 && l < g.L))) : (l >= 0 && l < g.L);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     w_tap = Wbase + ((long)tap * g.N + nrow) * g.K * ESZ + lhalf * 64;
   };
   set_tap(g_tap);
-  auto gload = [&](uint4 (&a4)[4], uint4 (&b4)[4]) {
+  auto gload = [&](uint4 (&a4)[4], uint4 (&b4)[4]) __attribute__((always_inline)) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     const bool k_on = !(last_half_empty && g_ks == ksteps - 1 && lhalf == 1);
     const int koff = g_ks * ROW_BYTES;
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       set_tap(++g_tap);
     }
   };
+  auto to_lds = [&](char* stage, const uint4 (&a4)[4], const uint4 (&b4)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(stage + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = a4[i];
+      *(uint4*)(stage + TILE + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = b4[i];
+    }
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -127,29 +135,26 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
-  auto step = [&](int it, uint4 (&a4)[4], uint4 (&b4)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(ldsA + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = a4[i];
-      *(uint4*)(ldsB + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = b4[i];
-    }
-    __syncthreads();
-    if (stamp && tid == 0 && it == it_begin) stamp[1] = (long long)__builtin_amdgcn_s_memrealtime();
-    if (it + PF < it_end) gload(a4, b4);
+  // Step `it` of register set u: its operands already sit in stage u & 1.  The fragments are read, the next step's
+  // registers go to the other stage and are refilled from memory, then the MFMAs run: one barrier per step.
+  auto step = [&](int it, int u, uint4 (&an)[4], uint4 (&bn)[4]) __attribute__((always_inline)) {
+    const char* cur = lds + (u & 1) * STAGE;
+    char* nxt = lds + ((u + 1) & 1) * STAGE;
     // Each lane takes 32 contiguous bytes of its row at byte 64*h + 32*fh of the slice.  The k order seen by the
     // MFMA is a permutation of the true k, identical for A and B, so the sum over k is unchanged.
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint4 fa[2][2], fb[2][2];
+    uint4 fa[2][2], fb[2][2];
+    auto read_frags = [&](int h) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const char* pa = ldsA + (wr * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
+        const char* pa = cur + (wr * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
         fa[i][0] = *(const uint4*)pa;
         fa[i][1] = *(const uint4*)(pa + 16);
-        const char* pb = ldsB + (wc * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
+        const char* pb = cur + TILE + (wc * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
         fb[i][0] = *(const uint4*)pb;
         fb[i][1] = *(const uint4*)(pb + 16);
       }
+    };
+    auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -170,17 +175,31 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
             }
           }
         }
+    };
+    read_frags(0);
+    if (it + 1 < it_end) {
+      to_lds(nxt, an, bn);
+      if (it + 1 + PF < it_end) gload(an, bn);
     }
+    multiply();
+    read_frags(1);
+    multiply();
     __syncthreads();
   };
 
 #pragma unroll
   for (int u = 0; u < PF; ++u)
     if (it_begin + u < it_end) gload(ra[u], rb[u]);
+  if (it_begin < it_end) {
+    to_lds(lds, ra[0], rb[0]);
+    if (it_begin + PF < it_end) gload(ra[0], rb[0]);
+  }
+  __syncthreads();
+  if (stamp && tid == 0) stamp[1] = (long long)__builtin_amdgcn_s_memrealtime();
   for (int it = it_begin; it < it_end; it += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-      if (it + u < it_end) step(it + u, ra[u], rb[u]);
+      if (it + u < it_end) step(it + u, u, ra[(u + 1) % PF], rb[(u + 1) % PF]);
   }
 
   if (stamp && tid == 0) stamp[2] = (long long)__builtin_amdgcn_s_memrealtime();

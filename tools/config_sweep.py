@@ -1,6 +1,6 @@
 """OA-DM step time of BASELINE.json's other configurations (bf16, graph replay), with the per-kind kernel shares of
-probed steps: config 4 geometry (640M, L=512, B per sub-batch) and config 5 (38M, B=1024, L=1024).
-    python tools/config_sweep.py [cfg4|cfg5|cfg2] ..."""
+probed steps: config 1 (38M, B=1, L=100: the reference notebook's case), config 4 geometry (640M, L=512, B per sub-batch) and config 5 (38M, B=1024, L=1024).
+    python tools/config_sweep.py [cfg1|cfg2|cfg4|cfg4b|cfg5] ..."""
 import sys
 import time
 
@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, ".")
 from evodiff_amd import pretrained  # noqa: E402
 
-CASES = {"cfg2": ("640M", 64, 256, 32), "cfg4": ("640M", 64, 512, 32), "cfg4b": ("640M", 128, 512, 16),
+CASES = {"cfg1": ("38M", 1, 100, 100), "cfg2": ("640M", 64, 256, 32), "cfg4": ("640M", 64, 512, 32), "cfg4b": ("640M", 128, 512, 16),
          "cfg5": ("38M", 1024, 1024, 12)}
 dev = torch.device("cuda", 0)
 for name in (sys.argv[1:] or ["cfg4", "cfg5"]):

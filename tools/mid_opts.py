@@ -15,7 +15,7 @@ m, _, tok, _ = pretrained.OA_DM_640M(random_init=True)
 m.precision = "bf16"
 L, n = 256, 32
 batches = [int(b) for b in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 16, 24, 32, 48]
-combos = [(32, 512, 130), (256, 512, 130), (256, 1024, 130), (256, 2048, 130), (32, 512, 64), (32, 512, 32), (256, 1024, 64)]
+combos = [(32, 512, 130), (256, 1024, 130), (32, 512, 64), (256, 1024, 200)]
 for B in batches:
     order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
     uni = torch.rand((n, B), device=dev)
