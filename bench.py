@@ -79,6 +79,72 @@ def measured_traffic(args):
         return None
 
 
+def strong_scaling(args, model, tokenizer, dev, world, rank):
+    """BASELINE config 4's form: a fixed number of sequences, sharded over the ranks (contiguous shards, no collective
+    on the data path), each rank sampling its shard in sub-batches; the finished sequences are all-gathered once per
+    step.  One "step" = the whole job.  Order and uniforms of a sub-batch are seeded by the global index of its first
+    sequence, so the sampled sequences do not depend on the number of ranks when the shards split on sub-batch
+    boundaries."""
+    import torch.distributed as dist
+    from evodiff_amd.parallel import gather_sequences, shard_range
+    N, L, Bsub = args.total_sequences, args.seq_len, args.batch
+    n_draw = len(tokenizer.all_aas) - 6
+    lo, hi = shard_range(N, rank, world)
+    subs = [(a, min(a + Bsub, hi)) for a in range(lo, hi, Bsub)]
+    orders, uniforms = [], []
+    for a, b in subs:
+        orders.append(torch.from_numpy(np.random.default_rng(1000 + a).permutation(L).astype(np.int32)).to(dev))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(2000 + a)
+        uniforms.append(torch.rand((L, b - a), generator=gen, device=dev, dtype=torch.float32))
+    local = torch.empty((hi - lo, L), dtype=torch.long, device=dev)
+
+    def one_step():
+        local.fill_(tokenizer.mask_id)
+        for (a, b), order, uni in zip(subs, orders, uniforms):
+            model.oadm_sample(local[a - lo:b - lo], order, uni, n_draw)
+        return gather_sequences(local, N)                       # RCCL all-gather when world > 1
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    model.hip_handle(dev)
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert full.shape == (N, L) and int((full == tokenizer.mask_id).sum()) == 0 and int(full.max()) < n_draw
+    if rank == 0:
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        f_eff = f_eff_per_sequence(model.hparams, L) * L
+        rate = N * args.steps / elapsed
+        print(json.dumps({
+            "metric": f"sequences/sec, OA_DM_{args.model} len-{L} sampling", "value": rate, "unit": "sequences/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"OA_DM_{args.model} unconditional generate_oaardm, {N} sequences sharded over "
+                                   f"{world} GPU(s), sub-batches of {Bsub}, seq_len {L}",
+                       "global_batch": N, "seq_len": L, "parallelism": f"dp{world} (sequence sharding)"},
+            "step_roofline": {"flops_per_sequence": f_eff, "achieved": f_eff * rate / 1e12, "unit": "TFLOP/s",
+                              "frac": f_eff * rate / 1e12 / (peak * world)},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +157,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-every", type=int, default=64)
+    ap.add_argument("--total-sequences", type=int, default=0,
+                    help="strong-scaling form (BASELINE config 4): a step samples this many sequences in total, sharded "
+                         "over the ranks (evodiff_amd.parallel.shard_range) and sampled in sub-batches of --batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +181,9 @@ def main():
     model.use_graph = not args.no_graph
     B, L = args.batch, args.seq_len
     n_draw = len(tokenizer.all_aas) - 6
+
+    if args.total_sequences > 0:
+        return strong_scaling(args, model, tokenizer, dev, world, rank)
 
     total = args.warmup + args.steps
     # independent sequences: each rank samples its own shard with its own order/uniform streams
