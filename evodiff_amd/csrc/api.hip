@@ -119,7 +119,8 @@ struct ed_model {
   std::vector<DevBuf> Car;
   int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
-  int split_target = 512;      // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
+  int split_target = 1024;     // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
+  int tile64_max = 320;        // ED_OPT_TILE64_MAX: bf16 problems with at most this many 128 x 128 tiles use 64 x 64 tiles
   int partials_mb = 32;        // ED_OPT_PARTIALS_MB: size of that workspace (a cut needs ksplit x rows x N x 4 bytes)
   int split_min_iters = 4;     // ED_OPT_SPLIT_MIN_ITERS: K-steps (of 64 channels) a workgroup keeps at least
   bool fuse_reduce_ln = true;  // ED_OPT_FUSE_REDUCE_LN: the LayerNorm behind a split-K GEMM adds up the partial sums itself
@@ -256,8 +257,14 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s, GemmPro
     // Small problems in the fast path: a few workgroups streaming cold weights are latency-bound, so the K loop
     // is cut across workgroups (deterministic: partial sums to a workspace, added up in a fixed order).
     GemmProblem q = p;
+    // problems with few 128 x 128 tiles take 64 x 64 tiles: four times the workgroups before any K loop is cut, so
+    // fewer (or no) partial sums to write and add up
+    long tiles = (long)p.B * ((p.L + 127) / 128) * ((p.N + 127) / 128);
+    if (p.a_bf16 && tiles <= m->tile64_max) {
+      q.tile = 64;
+      tiles = (long)p.B * ((p.L + 63) / 64) * ((p.N + 63) / 64);
+    }
     if (p.a_bf16 && m->split_target > 0 && m->partials.p) {
-      const long tiles = (long)p.B * ((p.L + 127) / 128) * ((p.N + 127) / 128);
       const int iters = p.ntaps * ((p.K + 63) / 64);
       long ks = std::min<long>({m->split_target / tiles, (long)iters / m->split_min_iters, 16L});
       while (ks > 1 && (size_t)ks * p.B * p.L * p.N * 4 > m->partials.bytes) --ks;
@@ -1119,11 +1126,15 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   }
   if (kernel >= 100) {  // small-tile kernel with its K loop cut kernel - 100 ways + the reduction (bf16 only); stamps if set
     static DevBuf dbg_partials;
+    if (kernel >= 200) {  // 200 + ksplit: the same on 64 x 64 tiles
+      p.tile = 64;
+      kernel -= 100;
+    }
     p.ksplit = kernel - 100;
     if (!p.a_bf16 || p.ksplit < 1 || p.ksplit > 16) return fail(ED_EINVAL, "kernel 100 + ksplit: bf16, ksplit in [1, 16]");
     HIP_TRY(dbg_partials.ensure((size_t)p.ksplit * B * L * N * 4));
     p.partial = dbg_partials.as<float>();
-    const int64_t wgs = (int64_t)((N + 127) / 128) * B * ((L + 127) / 128) * p.ksplit;
+    const int64_t wgs = (int64_t)((N + p.tile - 1) / p.tile) * B * ((L + p.tile - 1) / p.tile) * p.ksplit;
     if (g_stamp_buf && g_stamp_cap >= 4 * wgs) p.stamps = g_stamp_buf;
     LAUNCH_TRY(launch_gemm_generic(p, s));
     if (p.ksplit > 1) LAUNCH_TRY(launch_reduce_partials(p, s));
@@ -1167,6 +1178,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_FUSE_REDUCE_LN:
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_REDUCE_LN takes 0 or 1");
       m->fuse_reduce_ln = value != 0;
+      break;
+    case ED_OPT_TILE64_MAX:
+      if (value < 0) return fail(ED_EINVAL, "ED_OPT_TILE64_MAX must be >= 0");
+      m->tile64_max = value;
       break;
     case ED_OPT_PARTIALS_MB:
       if (value < 1 || value > 4096) return fail(ED_EINVAL, "ED_OPT_PARTIALS_MB must be in [1, 4096]");

@@ -21,12 +21,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
+// Tile: 64 TM rows x 64 TM columns per 256-thread workgroup, TM = 2 (128 x 128) or 1 (64 x 64: four times as many
+// workgroups for problems that would leave most CUs without a 128 x 128 tile, instead of cutting their K loops as far).
 constexpr int ROW_BYTES = 128;   // bytes of K per tile row per K-step (32 fp32 / 64 bf16)
 constexpr int LDS_STRIDE = 144;  // 128 + 16 pad: the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
 
-template <bool BF16, bool OUT_BF16, bool RESID>
+template <bool BF16, bool OUT_BF16, bool RESID, int TM>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
+  constexpr int BM = 64 * TM, BN = 64 * TM;
+  constexpr int WT = 32 * TM;               // rows / columns of a wave's piece (TM x TM MFMA 32 x 32 tiles)
+  constexpr int NV = 2 * TM;                // 16-byte pieces per loader thread, operand and K-step
+  constexpr int TPR = 4 / TM;               // loader threads per tile row
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int KSTEP = ROW_BYTES / ESZ;
   constexpr int TILE = BM * LDS_STRIDE, STAGE = 2 * TILE;  // A tile + W tile of one K-step
@@ -43,8 +48,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   const int l0 = (blockIdx.y % tiles_per_seq) * BM;
   const int n0 = blockIdx.x * BN;
 
-  // loader role: thread -> (tile row, 64-byte half of the 128-byte K slice)
-  const int lrow = tid >> 1, lhalf = tid & 1;
+  // loader role: thread -> (tile row, NV consecutive 16-byte pieces of the 128-byte K slice)
+  const int lrow = tid / TPR, lbyte = (tid % TPR) * (NV * 16), lhalf = lbyte >> 6;
   const int ksteps = (g.K + KSTEP - 1) / KSTEP;   // the last slice may be half full (K is a multiple of 64 bytes)
   const int half_taps = g.center();
   const bool last_half_empty = (g.K % KSTEP) != 0;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   // small problem as long as its K loop).
   constexpr int PF = 4;
   static_assert(PF % 2 == 0, "the LDS stage of a step is the parity of its register set");
-  uint4 ra[PF][4], rb[PF][4];
+  uint4 ra[PF][NV], rb[PF][NV];
   int g_tap = it_begin / ksteps, g_ks = it_begin - g_tap * ksteps;
   const char *a_tap = nullptr, *w_tap = nullptr;  // this thread's A / W row of the current tap, at its 64-byte half
   bool row_on = false;
@@ -89,76 +94,76 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     const int l = l0 + lrow + shift;
     row_on = g.seq_rows > 0 ? (l0 + lrow < g.L && (g.a_unbounded || (l >= 0 && l < g.L))) : (l >= 0 && l < g.L);
     const long a_row = g.seq_rows > 0 ? a_row_grouped + shift : (long)b * g.a_seq_pitch + g.a_row0 + l;
-    a_tap = Abase + a_row * g.K * ESZ + lhalf * 64;
-    w_tap = Wbase + ((long)tap * g.N + nrow) * g.K * ESZ + lhalf * 64;
+    a_tap = Abase + a_row * g.K * ESZ + lbyte;
+    w_tap = Wbase + ((long)tap * g.N + nrow) * g.K * ESZ + lbyte;
   };
   set_tap(g_tap);
-  auto gload = [&](uint4 (&a4)[4], uint4 (&b4)[4]) __attribute__((always_inline)) {
+  auto gload = [&](uint4 (&a4)[NV], uint4 (&b4)[NV]) __attribute__((always_inline)) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     const bool k_on = !(last_half_empty && g_ks == ksteps - 1 && lhalf == 1);
     const int koff = g_ks * ROW_BYTES;
     if (k_on && row_on) {
       const uint4* p = (const uint4*)(a_tap + koff);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a4[i] = p[i];
+      for (int i = 0; i < NV; ++i) a4[i] = p[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a4[i] = z;
+      for (int i = 0; i < NV; ++i) a4[i] = z;
     }
     if (k_on && nrow < g.N) {
       const uint4* p = (const uint4*)(w_tap + koff);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) b4[i] = p[i];
+      for (int i = 0; i < NV; ++i) b4[i] = p[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) b4[i] = z;
+      for (int i = 0; i < NV; ++i) b4[i] = z;
     }
     if (++g_ks == ksteps) {
       g_ks = 0;
       set_tap(++g_tap);
     }
   };
-  auto to_lds = [&](char* stage, const uint4 (&a4)[4], const uint4 (&b4)[4]) __attribute__((always_inline)) {
+  auto to_lds = [&](char* stage, const uint4 (&a4)[NV], const uint4 (&b4)[NV]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(stage + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = a4[i];
-      *(uint4*)(stage + TILE + lrow * LDS_STRIDE + lhalf * 64 + i * 16) = b4[i];
+    for (int i = 0; i < NV; ++i) {
+      *(uint4*)(stage + lrow * LDS_STRIDE + lbyte + i * 16) = a4[i];
+      *(uint4*)(stage + TILE + lrow * LDS_STRIDE + lbyte + i * 16) = b4[i];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
   // Step `it` of register set u: its operands already sit in stage u & 1.  The fragments are read, the next step's
   // registers go to the other stage and are refilled from memory, then the MFMAs run: one barrier per step.
-  auto step = [&](int it, int u, uint4 (&an)[4], uint4 (&bn)[4]) __attribute__((always_inline)) {
+  auto step = [&](int it, int u, uint4 (&an)[NV], uint4 (&bn)[NV]) __attribute__((always_inline)) {
     const char* cur = lds + (u & 1) * STAGE;
     char* nxt = lds + ((u + 1) & 1) * STAGE;
     // Each lane takes 32 contiguous bytes of its row at byte 64*h + 32*fh of the slice.  The k order seen by the
     // MFMA is a permutation of the true k, identical for A and B, so the sum over k is unchanged.
-    uint4 fa[2][2], fb[2][2];
+    uint4 fa[TM][2], fb[TM][2];
     auto read_frags = [&](int h) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const char* pa = cur + (wr * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
+      for (int i = 0; i < TM; ++i) {
+        const char* pa = cur + (wr * WT + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
         fa[i][0] = *(const uint4*)pa;
         fa[i][1] = *(const uint4*)(pa + 16);
-        const char* pb = cur + TILE + (wc * 64 + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
+        const char* pb = cur + TILE + (wc * WT + i * 32 + fr) * LDS_STRIDE + h * 64 + fh * 32;
         fb[i][0] = *(const uint4*)pb;
         fb[i][1] = *(const uint4*)(pb + 16);
       }
     };
     auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TM; ++j) {
           if constexpr (BF16) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -205,15 +210,15 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   if (stamp && tid == 0) stamp[2] = (long long)__builtin_amdgcn_s_memrealtime();
   // Element (i, j, r) of this lane sits at tile row 32 i + (r & 3) + 8 (r >> 2) + 4 fh, tile column 32 j + fr: the lane
   // part of the offset is computed once, the rest are compile-time multiples of N (32-bit: a tile spans 128 rows).
-  const int row_w = l0 + wr * 64, col_w = n0 + wc * 64;            // first row / column of this wave's 64 x 64 piece
+  const int row_w = l0 + wr * WT, col_w = n0 + wc * WT;            // first row / column of this wave's piece
   const int lane_off = 4 * fh * g.N + fr;
   const int row_lim = g.L - row_w - 4 * fh;                         // rows 32 i + c(r) below this exist
   if (g.ksplit > 1) {  // raw partial sums; bias, residual and rounding happen in the reduction
     float* part = g.partial + ((long)blockIdx.z * g.B * g.L + (long)b * g.L + row_w) * g.N + col_w;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TM; ++j) {
         if (col_w + j * 32 + fr >= g.N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -235,9 +240,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
     const float* const rbase = RESID ? g.resid + ((orow * g.resid_mul + rsel) * g.N + col_w) : nullptr;
     const int lane_roff = 4 * fh * g.resid_mul * g.N + fr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TM; ++j) {
         if (col_w + j * 32 + fr >= g.N) continue;
         const float bias = g.bias[col_w + j * 32 + fr];
 #pragma unroll
@@ -256,15 +261,15 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmProblem g) {
   // row groups: output and residual rows addressed per sequence
   const int osel = g.out_sel.get();
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 64 + j * 32 + fr;
+    for (int j = 0; j < TM; ++j) {
+      const int n = n0 + wc * WT + j * 32 + fr;
       if (n >= g.N) continue;
       const float bias = g.bias[n];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int l = l0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int l = l0 + wr * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (l >= g.L) continue;
         const unsigned bs = (unsigned)l / (unsigned)g.seq_rows, ls = (unsigned)l - bs * (unsigned)g.seq_rows;
         const long o = ((long)bs * g.out_pitch + osel + ls) * g.N + n;
@@ -329,9 +334,15 @@ hipError_t launch_gemm_generic(const GemmProblem& p, hipStream_t stream) {
   if (p.resid && p.out_bf16) return hipErrorInvalidValue;
   if (p.ksplit < 1 || (p.ksplit > 1 && !p.partial)) return hipErrorInvalidValue;
   if (p.seq_rows > 0 && (p.B != 1 || p.L % p.seq_rows != 0)) return hipErrorInvalidValue;
-  dim3 grid((p.N + BN - 1) / BN, (unsigned)(p.B * ((p.L + BM - 1) / BM)), (unsigned)p.ksplit);
+  if (p.tile != 128 && p.tile != 64) return hipErrorInvalidValue;
+  const int T = p.tile;
+  dim3 grid((p.N + T - 1) / T, (unsigned)(p.B * ((p.L + T - 1) / T)), (unsigned)p.ksplit);
   dim3 block(256);
-#define ED_LAUNCH(BF, OB, RS) hipLaunchKernelGGL((gemm_generic_kernel<BF, OB, RS>), grid, block, 0, stream, p)
+#define ED_LAUNCH(BF, OB, RS)                                                                        \
+  do {                                                                                               \
+    if (T == 128) hipLaunchKernelGGL((gemm_generic_kernel<BF, OB, RS, 2>), grid, block, 0, stream, p); \
+    else hipLaunchKernelGGL((gemm_generic_kernel<BF, OB, RS, 1>), grid, block, 0, stream, p);         \
+  } while (0)
   if (p.a_bf16) {
     if (p.resid) ED_LAUNCH(true, false, true);
     else if (p.out_bf16) ED_LAUNCH(true, true, false);

@@ -73,6 +73,7 @@ struct GemmProblem {
   bool a_unbounded = false;
   PosBit a_sel, out_sel;
   long out_pitch = 0, resid_pitch = 0;
+  int tile = 128;       // generic kernel only: 128 x 128 or 64 x 64 output tile per workgroup
   int ksplit = 1;       // generic kernel only: the K loop is cut into ksplit ranges (grid.z); range z writes its raw fp32
   float* partial = nullptr;  //   sums to partial[z][B*L][N] and launch_reduce_partials adds them up in a fixed order
   long long* stamps = nullptr;  // diagnostics (ablate == 7): per tile {shader cycles, 100-MHz ticks} of the K loop

@@ -153,14 +153,16 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
  *   ED_OPT_MIN_TUNED_TILES (default 130): GEMMs with fewer tiles than this (tiles of the height the tuned kernel
  *     would pick: 128 rows up to 128 tiles of 256 rows, 256 rows above) use the small-tile kernel instead of the
  *     tuned one (0 = tuned kernel whenever the shape allows).
- *   ED_OPT_SPLIT_TARGET (default 512): bf16 GEMMs on the small-tile kernel with fewer workgroups than this
+ *   ED_OPT_SPLIT_TARGET (default 1024): bf16 GEMMs on the small-tile kernel with fewer workgroups than this
  *     have their K loop cut across workgroups (partial sums added in a fixed order); 0 = never.
  *   ED_OPT_FUSE_REDUCE_LN (default 1): the LayerNorm behind such a GEMM adds up the partial sums itself (one
  *     launch instead of reduction + LayerNorm; same order of additions).  0 = separate reduction launch.
  *   ED_OPT_SPLIT_MIN_ITERS (default 4): K-steps of 64 channels every workgroup of a cut K loop keeps at least.
+ *   ED_OPT_TILE64_MAX (default 320): bf16 GEMMs on the small-tile kernel with at most this many 128 x 128 tiles use
+ *     64 x 64 tiles (four times the workgroups before any K loop is cut); 0 = never.
  *   ED_OPT_PARTIALS_MB (default 32): size in MiB of the partial-sum workspace (a cut needs ksplit x rows x N x 4 B). */
 enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1, ED_OPT_SPLIT_TARGET = 2, ED_OPT_INCREMENTAL = 3,
-       ED_OPT_FUSE_REDUCE_LN = 4, ED_OPT_SPLIT_MIN_ITERS = 5, ED_OPT_PARTIALS_MB = 6 };
+       ED_OPT_FUSE_REDUCE_LN = 4, ED_OPT_SPLIT_MIN_ITERS = 5, ED_OPT_PARTIALS_MB = 6, ED_OPT_TILE64_MAX = 7 };
 int ed_model_set_option(ed_model* m, int option, int value);
 
 /* Measurement hooks (no counterpart in the reference).  With a probe interval n > 0, every n-th

@@ -320,6 +320,13 @@ def test_fused_split_k_layernorm_matches_separate_reduction(dev, cfg, B, L):
         assert rel_err(logits[-1], want) < BF16_TOL
     assert rel_err(logits[0], logits[1]) < 4e-3
     assert np.abs(probs[0][0] - probs[1][0]).max() < 4e-3
+    # 64 x 64 tiles for the same problems (ED_OPT_TILE64_MAX): another cut of the K loops, the same sums
+    m.set_option("fuse_reduce_ln", 1)
+    m.set_option("tile64_max", 100000)
+    small = m(x.to(dev), zeros.to(dev)).cpu().numpy()
+    assert rel_err(small, want) < BF16_TOL and rel_err(small, logits[0]) < 4e-3
+    m.precision = "fp32"                       # fp32 problems keep the 128 x 128 tiles: the validation path is unchanged
+    assert rel_err(m(x.to(dev), zeros.to(dev)).cpu().numpy(), want) < FP32_TOL
 
 
 def test_640m_steps_vs_oracle(dev):

@@ -30,7 +30,7 @@ def test_python_option_names_match_the_header_enum():
     from evodiff_amd import _lib
     header = open(os.path.join(ROOT, "include", "evodiff_hip.h")).read()
     enum = re.search(r"enum\s*\{\s*(ED_OPT_[^}]*)\}", header).group(1)
-    declared = {name[len("ED_OPT_"):].lower(): int(value) for name, value in re.findall(r"(ED_OPT_[A-Z_]+)\s*=\s*(\d+)", enum)}
+    declared = {name[len("ED_OPT_"):].lower(): int(value) for name, value in re.findall(r"(ED_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", enum)}
     assert declared == _lib.OPTIONS
     for name in declared:                       # every option is documented in the header's comment block
         assert "ED_OPT_" + name.upper() + " (default" in header, name

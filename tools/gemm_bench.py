@@ -45,7 +45,8 @@ def main():
 
     stamps = None
     if a.kernel >= 100:
-        wgs = ((a.N + 127) // 128) * B * ((L + 127) // 128) * (a.kernel - 100)
+        tile, ks = (64, a.kernel - 200) if a.kernel >= 200 else (128, a.kernel - 100)
+        wgs = ((a.N + tile - 1) // tile) * B * ((L + tile - 1) // tile) * ks
         stamps = torch.zeros(4 * wgs, dtype=torch.int64, device=dev)
         _lib.check(lib.ed_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()))
     elif a.kernel == 9:
