@@ -1,5 +1,5 @@
-"""Mid-batch OA-DM step time (640M, L=256, bf16, graph replay) under the kernel-choice options:
-ED_OPT_PARTIALS_MB x ED_OPT_SPLIT_TARGET x ED_OPT_MIN_TUNED_TILES."""
+"""Mid-batch OA-DM step time (640M, L=256, bf16, graph replay) under the kernel-choice options
+ED_OPT_MIN_TUNED_TILES x ED_OPT_TILE64_MAX (x ED_OPT_PARTIALS_MB)."""
 import sys
 import time
 
@@ -14,14 +14,14 @@ torch.manual_seed(0)
 m, _, tok, _ = pretrained.OA_DM_640M(random_init=True)
 m.precision = "bf16"
 L, n = 256, 32
-batches = [int(b) for b in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 16, 24, 32, 48]
-combos = [(32, 512, 130), (256, 1024, 130), (32, 512, 64), (256, 1024, 200)]
+batches = [int(b) for b in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 24, 32, 48]
+combos = [(130, 320, 32), (200, 320, 32), (200, 1000, 256), (260, 1000, 256), (400, 1000, 256), (400, 2000, 256)]
 for B in batches:
     order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
     uni = torch.rand((n, B), device=dev)
-    for pmb, target, mtt in combos:
+    for mtt, t64, pmb in combos:
         m.set_option("partials_mb", pmb)
-        m.set_option("split_target", target)
+        m.set_option("tile64_max", t64)
         m.set_option("min_tuned_tiles", mtt)
         best = 1e9
         for rep in range(3):
@@ -31,4 +31,4 @@ for B in batches:
             m.oadm_sample(sample, order, uni, 21)
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / n)
-        print(f"B={B:3d} partials_mb={pmb} target={target} min_tuned_tiles={mtt}: {best * 1e3:.3f} ms/step", flush=True)
+        print(f"B={B:3d} min_tuned_tiles={mtt} tile64_max={t64} partials_mb={pmb}: {best * 1e3:.3f} ms/step", flush=True)
