@@ -266,7 +266,9 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s, GemmPro
     }
     if (p.a_bf16 && m->split_target > 0 && m->partials.p) {
       const int iters = p.ntaps * ((p.K + 63) / 64);
-      long ks = std::min<long>({m->split_target / tiles, (long)iters / m->split_min_iters, 16L});
+      // few tiles: cutting the K loops beyond ~4 workgroups per tile costs more in partial sums than it saves (measured)
+      const long target = std::min<long>(m->split_target, std::max<long>(512, 4 * tiles));
+      long ks = std::min<long>({target / tiles, (long)iters / m->split_min_iters, 16L});
       while (ks > 1 && (size_t)ks * p.B * p.L * p.N * 4 > m->partials.bytes) --ks;
       if (ks > 1) {
         q.ksplit = (int)ks;
