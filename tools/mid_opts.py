@@ -15,7 +15,7 @@ m, _, tok, _ = pretrained.OA_DM_640M(random_init=True)
 m.precision = "bf16"
 L, n = 256, 32
 batches = [int(b) for b in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 24, 32, 48]
-combos = [(130, 320, 32), (200, 320, 32), (200, 1000, 256), (260, 1000, 256), (400, 1000, 256), (400, 2000, 256)]
+combos = [(130, 320, 32), (64, 320, 32), (100, 320, 32), (200, 320, 32), (130, 160, 32), (130, 640, 32)]
 for B in batches:
     order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
     uni = torch.rand((n, B), device=dev)
