@@ -154,7 +154,8 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
  *     would pick: 128 rows up to 128 tiles of 256 rows, 256 rows above) use the small-tile kernel instead of the
  *     tuned one (0 = tuned kernel whenever the shape allows).
  *   ED_OPT_SPLIT_TARGET (default 1024): bf16 GEMMs on the small-tile kernel with fewer workgroups than this
- *     have their K loop cut across workgroups (partial sums added in a fixed order); 0 = never.
+ *     have their K loop cut across workgroups, up to this many (at most ~4 per tile when there are few tiles, and 16
+ *     ways); partial sums are added in a fixed order; 0 = never.
  *   ED_OPT_FUSE_REDUCE_LN (default 1): the LayerNorm behind such a GEMM adds up the partial sums itself (one
  *     launch instead of reduction + LayerNorm; same order of additions).  0 = separate reduction launch.
  *   ED_OPT_SPLIT_MIN_ITERS (default 4): K-steps of 64 channels every workgroup of a cut K loop keeps at least.
