@@ -631,7 +631,8 @@ def test_causal_forward_vs_oracle(dev, base, B, L):
     assert torch.equal(got[:, :p + 1], got2[:, :p + 1]) and not torch.equal(got[:, p + 1:], got2[:, p + 1:])
 
 
-@pytest.mark.parametrize("base,precision,max_len", [(TINY_WIDE, "fp32", 48), (TINY, "fp32", 300), (TINY_WIDE, "bf16", 48)])
+@pytest.mark.parametrize("base,precision,max_len", [(TINY_WIDE, "fp32", 48), (TINY, "fp32", 300), (TINY_WIDE, "bf16", 48),
+                                                    (BIG640, "bf16", 24)])   # wide enough for every GEMM's K loop to be cut
 def test_autoregressive_sampler_vs_oracle(dev, base, precision, max_len):
     """generate_autoreg (generate.py:217-256) on a causal model.  The oracle re-runs the whole
     growing prefix at every step like the reference; ed_ar_sample computes one new row per layer from cached
