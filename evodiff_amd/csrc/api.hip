@@ -120,6 +120,8 @@ struct ed_model {
   int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 1024;     // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
+  int tuned_split_min_rows = 0;  // ED_OPT_TUNED_SPLIT_MIN_ROWS: problems of at least this many rows that are too small for the
+                                 //   tuned kernel as it is run it with a cut K loop (0 = never)
   int tile64_max = 320;        // ED_OPT_TILE64_MAX: bf16 problems with at most this many 128 x 128 tiles use 64 x 64 tiles
   int partials_mb = 32;        // ED_OPT_PARTIALS_MB: size of that workspace (a cut needs ksplit x rows x N x 4 bytes)
   int split_min_iters = 4;     // ED_OPT_SPLIT_MIN_ITERS: K-steps (of 64 channels) a workgroup keeps at least
@@ -246,13 +248,38 @@ bool use_tuned_gemm(const ed_model* m, const GemmProblem& p) {
 // `deferred`: the caller's next launch is the LayerNorm of this result.  If the K loop gets cut across workgroups the
 // reduction launch is left out and *deferred receives the problem with its partial sums (ksplit > 1) for
 // run_ln_after, which then adds them up inside the LayerNorm kernel.
+// Mid-size problems (ED_OPT_TUNED_SPLIT_MIN_ROWS <= rows, fewer tuned tiles than ED_OPT_MIN_TUNED_TILES): how many ways
+// the tuned kernel's K loop is cut so that about one workgroup per CU runs; 1 = not this path.
+int tuned_split(const ed_model* m, const GemmProblem& p) {
+  if (m->tuned_split_min_rows <= 0 || !p.a_bf16 || !gemm_bf16_supported(p) || !m->partials.p) return 1;
+  const long rows = (long)p.B * p.L;
+  if (rows < m->tuned_split_min_rows || gemm_bf16_tile_rows(p) != 128) return 1;
+  const long tiles = (long)p.B * ((p.L + 127) / 128) * (p.N % 320 == 0 ? p.N / 320 : p.N / 256);
+  if (tiles >= m->min_tuned_tiles) return 1;
+  const long steps = (long)p.ntaps * (p.K / 64);
+  long ks = std::min<long>({(256 + tiles - 1) / tiles, steps / 4, 16L});
+  while (ks > 1 && (size_t)ks * rows * p.N * 4 > m->partials.bytes) --ks;
+  return (int)std::max<long>(ks, 1);
+}
+
 int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s, GemmProblem* deferred = nullptr) {
   if (deferred) deferred->ksplit = 1;
   Probe pr(m, s);
   LAUNCH_TRY(pr.begin());
+  const int tuned_ks = tuned_split(m, p);
   if (use_tuned_gemm(m, p)) {
     LAUNCH_TRY(launch_gemm_bf16(p, s));
     if (kind == ED_K_CONV && !conv_window_supported(p)) kind = ED_K_CONV_OTHER;
+  } else if (tuned_ks > 1) {
+    // mid-size problems: too few tiles for the tuned kernel as it is, too many rows for the small-tile kernel to be
+    // efficient - the tuned kernel (128-row tiles) with its K loop cut across workgroups
+    GemmProblem q = p;
+    q.ksplit = tuned_ks;
+    q.partial = m->partials.as<float>();
+    LAUNCH_TRY(launch_gemm_bf16(q, s));
+    if (deferred && m->fuse_reduce_ln && reduce_ln_supported(q)) *deferred = q;
+    else LAUNCH_TRY(launch_reduce_partials(q, s));
+    if (kind == ED_K_CONV) kind = ED_K_CONV_OTHER;
   } else {
     // Small problems in the fast path: a few workgroups streaming cold weights are latency-bound, so the K loop
     // is cut across workgroups (deterministic: partial sums to a workspace, added up in a fixed order).
@@ -1126,7 +1153,15 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
       p.stamps = g_stamp_buf;
     }
   }
-  if (kernel >= 100) {  // small-tile kernel with its K loop cut kernel - 100 ways + the reduction (bf16 only); stamps if set
+  if (kernel >= 300) {  // tuned kernel with its K loop cut kernel - 300 ways + the reduction
+    static DevBuf dbg_partials2;
+    p.ksplit = kernel - 300;
+    if (!gemm_bf16_supported(p) || p.ksplit < 2 || p.ksplit > 16) return fail(ED_EINVAL, "kernel 300 + ksplit: tuned shape, ksplit in [2, 16]");
+    HIP_TRY(dbg_partials2.ensure((size_t)p.ksplit * B * L * N * 4));
+    p.partial = dbg_partials2.as<float>();
+    LAUNCH_TRY(launch_gemm_bf16(p, s));
+    LAUNCH_TRY(launch_reduce_partials(p, s));
+  } else if (kernel >= 100) {  // small-tile kernel with its K loop cut kernel - 100 ways + the reduction (bf16 only); stamps if set
     static DevBuf dbg_partials;
     if (kernel >= 200) {  // 200 + ksplit: the same on 64 x 64 tiles
       p.tile = 64;
@@ -1180,6 +1215,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_FUSE_REDUCE_LN:
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_REDUCE_LN takes 0 or 1");
       m->fuse_reduce_ln = value != 0;
+      break;
+    case ED_OPT_TUNED_SPLIT_MIN_ROWS:
+      if (value < 0) return fail(ED_EINVAL, "ED_OPT_TUNED_SPLIT_MIN_ROWS must be >= 0");
+      m->tuned_split_min_rows = value;
       break;
     case ED_OPT_TILE64_MAX:
       if (value < 0) return fail(ED_EINVAL, "ED_OPT_TILE64_MAX must be >= 0");

@@ -48,8 +48,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // WM: waves along M (2 along N always).  4 = the 256-row tile; 2 = a 128-row tile with 4 waves (one per SIMD) for
 // problems that would fill less than half the chip with 256-row tiles: every wave keeps its 64 x BN/2 sub-tile and
 // copies twice as many weight groups.
-template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0, int WM = 4>
+// SPLIT: the K loop of a tile is cut into g.ksplit ranges (blockIdx.y); range z accumulates from zero and stores raw
+// fp32 sums to g.partial[z] (bias, residual and rounding happen where the ranges are added up: launch_reduce_partials
+// or the LayerNorm behind the GEMM).  For problems with too few tiles to fill the chip.
+template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0, int WM = 4, bool SPLIT = false>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
+  static_assert(!SPLIT || (!OUT_BF16 && !RESID && RT == 0 && ABLATE == 0), "split form: raw fp32 partial sums only");
   constexpr int BM = WM * 64;       // (shadows the file-scope 256)
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
@@ -87,7 +91,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   int tap_lo = 0, tap_hi = g.ntaps - 1;
   while (tap_lo < g.ntaps && l0 + (tap_lo - half_taps) * g.dilation + BM <= 0) ++tap_lo;
   while (tap_hi >= 0 && l0 + (tap_hi - half_taps) * g.dilation >= g.L) --tap_hi;
-  const int T = (tap_hi - tap_lo + 1) * ksteps;  // number of steps
+  const int T_all = (tap_hi - tap_lo + 1) * ksteps;  // number of steps of the tile
+  int t_first = 0, T = T_all;                       // this workgroup's range of them
+  if constexpr (SPLIT) {
+    const int chunk = (T_all + g.ksplit - 1) / g.ksplit;
+    t_first = (int)blockIdx.y * chunk;
+    T = (t_first + chunk < T_all ? t_first + chunk : T_all) - t_first;
+    if (T < 0) T = 0;
+    if (t_first > T_all) t_first = T_all;
+  }
+  const int tap_first = t_first / ksteps, kk_first = t_first - tap_first * ksteps;
 
   // ---- DMA addressing.  Lane -> (row in 8-row group, physical chunk); logical chunk = physical ^ swizzle.
   // Group bases are multiples of 8 rows, so (row >> 1) & 7 = 4 * (group parity) + (lane >> 4).
@@ -98,12 +111,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   const unsigned grp_bytes = (unsigned)(8 * row_bytes);
   // wave-uniform bases of the copy stream (this wave's first A / W group), advanced step by step
   const char* a_dma = (const char*)g.A +
-                      ((long)b * g.a_seq_pitch + g.a_row0 + l0 + (long)(tap_lo - half_taps) * g.dilation + wid * 32) *
-                          row_bytes;
-  const char* w_dma = (const char*)g.W + ((long)tap_lo * g.N + n0) * row_bytes;
+                      ((long)b * g.a_seq_pitch + g.a_row0 + l0 + (long)(tap_lo + tap_first - half_taps) * g.dilation + wid * 32) *
+                          row_bytes + (long)kk_first * ROW_B;
+  const char* w_dma = (const char*)g.W + ((long)(tap_lo + tap_first) * g.N + n0) * row_bytes + (long)kk_first * ROW_B;
   const unsigned w_lane_extra = (unsigned)((lane >> 5) * 4 * row_bytes);  // permuted rows: group row k reads channel + 4*(k >> 2)
   const long a_tap_step = (long)(g.dilation - 1) * row_bytes + ROW_B, w_tap_step = (long)(g.N - 1) * row_bytes + ROW_B;
-  int dma_kk = 0, dma_t = 0;
+  int dma_kk = kk_first, dma_t = 0;
 
   // piece j (0 .. N_DMA-1) of the copy of step dma_t into stage dma_t & 1
   auto dma_piece = [&](int j) {
@@ -144,7 +157,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   f32x4 acc[NJ][4];
 #pragma unroll
   for (int jn = 0; jn < NJ; ++jn) {
-    const f32x4 bj = *(const f32x4*)(g.bias + nb + 32 * (jn >> 1) + 4 * (jn & 1));
+    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!SPLIT) bj = *(const f32x4*)(g.bias + nb + 32 * (jn >> 1) + 4 * (jn & 1));
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) acc[jn][ip] = bj;
   }
@@ -281,8 +295,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
           pk.w = (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16);
           *(uint4*)((bf16_t*)g.out + o + 32 * jp) = pk;
         } else {
-          *(f32x4*)((float*)g.out + o + 32 * jp) = v;
-          *(f32x4*)((float*)g.out + o + 32 * jp + 4) = w;
+          float* const outf = SPLIT ? g.partial + (long)blockIdx.y * g.B * g.L * g.N : (float*)g.out;
+          *(f32x4*)(outf + o + 32 * jp) = v;
+          *(f32x4*)(outf + o + 32 * jp + 4) = w;
         }
       }
     }
@@ -305,6 +320,12 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   const int tiles_n = p.N / (NT * 64);
   const int tiles_total = p.B * ((p.L + BMT - 1) / BMT) * tiles_n;
   const dim3 grid(tiles_total), block(WM * 128);
+  if (p.ksplit > 1) {  // K loop cut across workgroups: raw partial sums
+    if (!p.partial || p.ablate != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, false, 0, 0, WM, true>), dim3(tiles_total, p.ksplit), block, 0,
+                       stream, p, tiles_n, tiles_total);
+    return hipGetLastError();
+  }
 #define ED_GO(OB, RS, AB) \
   hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB, 0, WM>), grid, block, 0, stream, p, tiles_n, tiles_total)
   if (p.ablate == 1) ED_GO(false, false, 1);
@@ -354,7 +375,9 @@ bool gemm_bf16_supported(const GemmProblem& p) {
 
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream) {
   if (!gemm_bf16_supported(p)) return hipErrorInvalidValue;
-  if ((p.ablate == 0 || p.ablate >= 4) && conv_window_supported(p)) return launch_conv_window(p, stream);
+  if (p.ksplit < 1 || p.ksplit > 64) return hipErrorInvalidValue;
+  // (a cut K loop always takes the per-tap form: its step order is the one the ranges are defined on)
+  if (p.ksplit == 1 && (p.ablate == 0 || p.ablate >= 4) && conv_window_supported(p)) return launch_conv_window(p, stream);
   if (p.ntaps > 1) return p.N % 320 == 0 ? launch_nt<5, true>(p, stream) : launch_nt<4, true>(p, stream);
   return p.N % 320 == 0 ? launch_nt<5, false>(p, stream) : launch_nt<4, false>(p, stream);
 }

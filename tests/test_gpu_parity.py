@@ -325,6 +325,11 @@ def test_fused_split_k_layernorm_matches_separate_reduction(dev, cfg, B, L):
     m.set_option("tile64_max", 100000)
     small = m(x.to(dev), zeros.to(dev)).cpu().numpy()
     assert rel_err(small, want) < BF16_TOL and rel_err(small, logits[0]) < 4e-3
+    # the tuned kernel with a cut K loop for the same problems, where their shape allows it (ED_OPT_TUNED_SPLIT_MIN_ROWS)
+    m.set_option("tuned_split_min_rows", 256)
+    mid = m(x.to(dev), zeros.to(dev)).cpu().numpy()
+    assert rel_err(mid, want) < BF16_TOL and rel_err(mid, logits[0]) < 1e-2
+    m.set_option("tuned_split_min_rows", 0)
     m.precision = "fp32"                       # fp32 problems keep the 128 x 128 tiles: the validation path is unchanged
     assert rel_err(m(x.to(dev), zeros.to(dev)).cpu().numpy(), want) < FP32_TOL
 
