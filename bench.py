@@ -254,7 +254,7 @@ def main():
             # whole step against the same peak: algorithmic FLOPs of the model on this batch (in-range
             # taps only; work the pruning skips is NOT subtracted) / wall time
             "step_roofline": {"flops_per_sequence": f_eff, "achieved": f_eff * world * B * args.steps / elapsed / 1e12,
-                              "unit": "TFLOP/s", "frac": f_eff * world * B * args.steps / elapsed / 1e12 / peak,
+                              "unit": "TFLOP/s", "frac": f_eff * world * B * args.steps / elapsed / 1e12 / (peak * world),
                               "note": "denominator counts every position of every block; dependency-cone pruning "
                                       "and the incremental leading layers skip ~15 % of it in the OA-DM path"},
         }
