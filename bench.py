@@ -18,6 +18,7 @@ default config only.  cpu_baseline: the CPU oracle (a port of the reference's Py
 a bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -154,6 +155,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--model", default="640M", choices=["640M", "38M"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sampler", default="oadm", choices=["oadm", "d3pm"],
+                    help="oadm: BASELINE config 2 (the metric's configuration, default); d3pm: config 3 "
+                         "(D3PM_BLOSUM, every Q_t transition step of generate_d3pm per batch)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-every", type=int, default=64)
@@ -175,28 +179,44 @@ def main():
 
     from evodiff_amd import pretrained
     torch.manual_seed(0)                      # same synthetic weights on every rank
-    loader = pretrained.OA_DM_640M if args.model == "640M" else pretrained.OA_DM_38M
-    model, _, tokenizer, _ = loader(random_init=True)
+    d3pm = args.sampler == "d3pm"
+    if d3pm:
+        loader = pretrained.D3PM_BLOSUM_640M if args.model == "640M" else pretrained.D3PM_BLOSUM_38M
+        with contextlib.redirect_stdout(sys.stderr):       # the schedule builder prints its name, as the reference's does
+            model, _, tokenizer, _, T, Q_bar, Q = loader(return_all=True, random_init=True)
+        Q, Q_bar = Q.to(dev), Q_bar.to(dev)
+    else:
+        loader = pretrained.OA_DM_640M if args.model == "640M" else pretrained.OA_DM_38M
+        model, _, tokenizer, _ = loader(random_init=True)
     model.precision = args.precision
     model.use_graph = not args.no_graph
     B, L = args.batch, args.seq_len
     n_draw = len(tokenizer.all_aas) - 6
 
     if args.total_sequences > 0:
+        if d3pm:
+            raise SystemExit("--total-sequences is the OA-DM form of config 4")
         return strong_scaling(args, model, tokenizer, dev, world, rank)
 
     total = args.warmup + args.steps
     # independent sequences: each rank samples its own shard with its own order/uniform streams
     rng = np.random.default_rng(1000 + rank)
-    orders = [torch.from_numpy(rng.permutation(L).astype(np.int32)).to(dev) for _ in range(total)]
     gen = torch.Generator(device=dev)
     gen.manual_seed(2000 + rank)
-    uniforms = [torch.rand((L, B), generator=gen, device=dev, dtype=torch.float32) for _ in range(total)]
-    samples = [torch.full((B, L), tokenizer.mask_id, dtype=torch.long, device=dev) for _ in range(total)]
+    if d3pm:                                   # generate.py:266: a uniformly random start over the K classes
+        uniforms = [torch.rand((T, B, L), generator=gen, device=dev, dtype=torch.float32) for _ in range(total)]
+        samples = [torch.from_numpy(rng.integers(0, tokenizer.K, (B, L))).to(dev) for _ in range(total)]
+    else:
+        orders = [torch.from_numpy(rng.permutation(L).astype(np.int32)).to(dev) for _ in range(total)]
+        uniforms = [torch.rand((L, B), generator=gen, device=dev, dtype=torch.float32) for _ in range(total)]
+        samples = [torch.full((B, L), tokenizer.mask_id, dtype=torch.long, device=dev) for _ in range(total)]
     gathered = torch.empty((world * B, L), dtype=torch.long, device=dev) if world > 1 else None
 
     def one_step(i):
-        model.oadm_sample(samples[i], orders[i], uniforms[i], n_draw)
+        if d3pm:
+            model.d3pm_sample(samples[i], Q, Q_bar, uniforms[i], tokenizer.K)      # all T - 1 reverse steps
+        else:
+            model.oadm_sample(samples[i], orders[i], uniforms[i], n_draw)
         if world > 1:
             dist.all_gather_into_tensor(gathered, samples[i])      # RCCL over xGMI: the finished sequences
 
@@ -225,23 +245,28 @@ def main():
     stats = model.probe_read()
     model.probe(0)
     done = samples[-1]
-    assert int((done == tokenizer.mask_id).sum()) == 0 and int(done.max()) < n_draw, "sampling left masks behind"
+    if d3pm:
+        assert int(done.min()) >= 0 and int(done.max()) < tokenizer.K - 6, "last D3PM step draws canonical residues"
+    else:
+        assert int((done == tokenizer.mask_id).sum()) == 0 and int(done.max()) < n_draw, "sampling left masks behind"
 
     if rank == 0:
         conv = stats["conv"]
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-        f_eff = f_eff_per_sequence(model.hparams, L) * L      # L forwards per sequence
+        n_fwd = T - 1 if d3pm else L                           # denoiser forwards per sequence
+        f_eff = f_eff_per_sequence(model.hparams, L) * n_fwd
+        name = f"{'D3PM_BLOSUM' if d3pm else 'OA_DM'}_{args.model}"
         out = {
-            "metric": "sequences/sec, OA_DM_640M len-256 sampling",
+            "metric": f"sequences/sec, {name} len-{L} sampling",
             "value": world * B * args.steps / elapsed,
             "unit": "sequences/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"OA_DM_{args.model} unconditional generate_oaardm, batch {B} per GPU, "
-                                   f"seq_len {L} ({L} diffusion steps per batch), hipGraph replay "
+            "config": {"workload": f"{name} unconditional {'generate_d3pm' if d3pm else 'generate_oaardm'}, "
+                                   f"batch {B} per GPU, seq_len {L} ({n_fwd} diffusion steps per batch), hipGraph replay "
                                    f"{'off' if args.no_graph else 'on'}",
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world} (sequence sharding)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -255,10 +280,11 @@ def main():
             # taps only; work the pruning skips is NOT subtracted) / wall time
             "step_roofline": {"flops_per_sequence": f_eff, "achieved": f_eff * world * B * args.steps / elapsed / 1e12,
                               "unit": "TFLOP/s", "frac": f_eff * world * B * args.steps / elapsed / 1e12 / (peak * world),
-                              "note": "denominator counts every position of every block; dependency-cone pruning "
-                                      "and the incremental leading layers skip ~15 % of it in the OA-DM path"},
+                              "note": "denominator counts every position of every block" + ("" if d3pm else
+                                      "; dependency-cone pruning and the incremental leading layers skip ~15 % of it "
+                                      "in the OA-DM path")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not d3pm:      # the CPU leg times the metric's OA-DM loop
             out["cpu_baseline"] = cpu_baseline(L)
         print(json.dumps(out), flush=True)
     if world > 1:
