@@ -104,6 +104,9 @@ def strong_scaling(args, model, tokenizer, dev, world, rank):
         local.fill_(tokenizer.mask_id)
         for (a, b), order, uni in zip(subs, orders, uniforms):
             model.oadm_sample(local[a - lo:b - lo], order, uni, n_draw)
+            if rank == 0 and len(subs) > 2:            # a long job keeps its log moving (stderr; stdout stays one line)
+                torch.cuda.synchronize(dev)
+                print(f"[bench] sub-batch {a}..{b} of shard {lo}..{hi} done", file=sys.stderr, flush=True)
         return gather_sequences(local, N)                       # RCCL all-gather when world > 1
 
     def fence():
