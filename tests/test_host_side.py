@@ -234,3 +234,22 @@ def test_protein_alphabet_loaders():
     assert int((src == tok.mask_id).sum()) == int(timesteps[0]) == int(masks.sum())
     oracle = R.build_model(dict(R.MODEL_CONFIGS["38M"], n_tokens=30, causal=True), None, None)
     assert list(oracle.state_dict().keys()) == list(pretrained.LR_AR_38M(random_init=True)[0].state_dict().keys())
+
+
+def test_bench_flop_count_matches_survey_8d():
+    """bench.py's roofline denominator (algorithmic FLOPs, in-range taps only) against SURVEY.md §8d's per-token
+    figures: 640M at L = 256 / 512, 38M at L = 100 / 1024."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base = dict(n_tokens=31, d_embed=8, kernel_size=5, r=128)
+    big = dict(base, d_model=1280, d_hidden=1280, n_layers=56)
+    small = dict(base, d_model=1024, d_hidden=512, n_layers=16)
+    for hp, L, mflop_per_token in ((big, 256, 1147.5), (big, 512, 1216.1), (small, 100, 63.98), (small, 1024, 74.01)):
+        got = bench.f_eff_per_sequence(hp, L) / L / 1e6
+        assert abs(got - mflop_per_token) / mflop_per_token < 1e-3, (L, got, mflop_per_token)
+    line = json.load(open(os.path.join(root, "profiles", "r01_bench.json")))
+    assert abs(line["step_roofline"]["flops_per_sequence"] - bench.f_eff_per_sequence(big, 256) * 256) < 1e6
