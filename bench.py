@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E
 
 
 def cpu_baseline(L, seconds_budget=20.0):
@@ -287,6 +288,14 @@ def main():
                                       "; dependency-cone pruning and the incremental leading layers skip ~15 % of it "
                                       "in the OA-DM path")},
         }
+        if B * L <= 4096:
+            # weight-streaming regime (north_star: small-batch steps against the 8 TB/s HBM peak): every diffusion step
+            # reads each bf16 (fp32) weight once; bytes = parameters x element size, per step, over the wall time
+            n_param = sum(p.numel() for p in model.parameters())
+            wbytes = n_param * (2 if args.precision == "bf16" else 4)
+            gbs = wbytes * n_fwd * args.steps / elapsed / 1e9
+            out["small_batch_roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": gbs / PEAK_HBM_GBS, "weight_bytes_per_step": wbytes}
         if world == 1 and not args.no_cpu_baseline and not d3pm:      # the CPU leg times the metric's OA-DM loop
             out["cpu_baseline"] = cpu_baseline(L)
         print(json.dumps(out), flush=True)
