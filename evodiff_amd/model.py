@@ -75,14 +75,15 @@ class PositionalEncoding1D(nn.Module):
         self.d_model, self.length = d_model, length
 
     def table(self):
-        if self.d_model % 2 != 0:
-            raise ValueError("Cannot use sin/cos positional encoding with odd dim (got dim={:d})".format(self.d_model))
-        pe = torch.zeros(self.length, self.d_model)
-        position = torch.arange(0, self.length).unsqueeze(1)
-        div_term = torch.exp((torch.arange(0, self.d_model, 2, dtype=torch.float) * -(np.log(10000.0) / self.d_model)))
-        pe[:, 0::2] = torch.sin(position.float() * div_term)
-        pe[:, 1::2] = torch.cos(position.float() * div_term)
-        return pe
+        """(length, d_model) fp32: column 2j holds sin(t * w_j), column 2j+1 cos(t * w_j), w_j = 10000^(-2j/d_model)
+        evaluated as exp(2j * (-ln 10000 / d_model)) in fp32 like the reference, whose table this has to equal bit
+        for bit (tests/golden/tiny_timeenc.npz)."""
+        if self.d_model % 2:
+            raise ValueError("sin/cos timestep encoding needs an even width, got %d" % self.d_model)
+        rate = -(np.log(10000.0) / self.d_model)
+        omega = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float) * rate)          # (d_model / 2,)
+        angle = torch.arange(0, self.length).unsqueeze(1).float() * omega                      # (length, d_model / 2)
+        return torch.stack((torch.sin(angle), torch.cos(angle)), dim=2).reshape(self.length, self.d_model)
 
     def forward(self, x):
         return self.table().to(x.device)[x]

@@ -6,6 +6,7 @@ position order / uniform streams (seeded by GLOBAL sequence index, so results do
 captured graph.  There is no collective on the data path; the one exchange is the all-gather of the finished
 token tensors (RCCL over xGMI when the backend is "nccl"; gloo on CPU in the tests).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -20,6 +21,38 @@ def shard_range(n_sequences, rank, world_size):
 def shard_seeds(seed, lo, hi):
     """One RNG seed per global sequence index."""
     return [seed * 1000003 + i for i in range(lo, hi)]
+
+
+def global_sub_batches(lo, hi, batch):
+    """Cut the shard [lo, hi) along the GLOBAL grid of sub-batches: sub-batch j holds the sequences
+    [j * batch, (j + 1) * batch) whatever the number of ranks, and a rank samples the part of each that falls into its
+    shard, ``(a, b, j)`` with ``[a, b)`` inside sub-batch j.  One sampler call per piece: the position order is one
+    per call in the reference (generate.py:191-192), so it is seeded by j and every sequence sees the same order at any
+    world size, also when the shard size is not a multiple of ``batch``."""
+    pieces = []
+    a = lo
+    while a < hi:
+        j = a // batch
+        b = min(hi, (j + 1) * batch)
+        pieces.append((a, b, j))
+        a = b
+    return pieces
+
+
+def batch_order(seed, j, length):
+    """The position order of global sub-batch j (np.random.shuffle of arange(L) in the reference, generate.py:191-192)."""
+    return np.random.default_rng([int(seed), int(j)]).permutation(length).astype(np.int32)
+
+
+def sequence_uniforms(seed, lo, hi, shape):
+    """Pre-drawn uniforms of the sequences [lo, hi): one stream per GLOBAL sequence index, so a sequence draws the same
+    numbers on any rank of any world size.  Returns fp32 ``shape + (hi - lo,)`` (sequence index last: OA-DM wants
+    (n_steps, B)); D3PM callers move the axis."""
+    shape = tuple(shape)
+    out = np.empty(shape + (hi - lo,), dtype=np.float32)
+    for g in range(lo, hi):
+        out[..., g - lo] = np.random.default_rng([int(seed), int(g)]).random(shape, dtype=np.float32)
+    return out
 
 
 def gather_sequences(local_tokens, n_sequences):

@@ -43,7 +43,28 @@ def load_sequence_checkpoint(model_name, config_path, diffusion_timesteps, token
     # checkpoints were saved from DistributedDataParallel: strip the "module." prefix (pretrained.py:47-51)
     msd = {(k.split("module.")[1] if k.startswith("module.") else k): v for k, v in msd.items()}
     model.load_state_dict(msd)
+    check_mask_embedding(model, tokenizer, source=path_to_checkpoints or model_name)
     return model, tokenizer
+
+
+def check_mask_embedding(model, tokenizer, source="checkpoint"):
+    """Alphabet self-check on LOADED weights.  The reference builds its embedding with
+    ``padding_idx=tokenizer.mask_id`` (pretrained.py:39-40, model.py:97): that row is zero at init and never receives a
+    gradient, so a trained checkpoint has ``embedder.embedder.weight[mask_id] == 0`` - and no other all-zero row.  The
+    order of the last four special tokens of ``MSA_ALPHABET`` / ``PROTEIN_ALPHABET`` in ``evodiff_amd/constants.py``
+    is restated from the third-party ``sequence_models.constants`` from memory; if it were wrong, the zero row of a real
+    checkpoint would sit at another index and every mask token would be embedded as some other symbol.  Raises
+    ``ValueError`` naming the alphabet table instead of sampling garbage."""
+    weight = model.state_dict()["embedder.embedder.weight"]
+    mask_id = int(tokenizer.mask_id)
+    zero_rows = [int(i) for i in torch.nonzero(weight.abs().sum(dim=1) == 0).flatten()]
+    if zero_rows != [mask_id]:
+        raise ValueError(
+            "%s: embedder.embedder.weight has all-zero rows %s but the tokenizer's mask_id is %d. A checkpoint trained "
+            "with padding_idx=mask_id keeps exactly that row at zero, so the token order in evodiff_amd/constants.py "
+            "(MSA_ALPHABET / PROTEIN_ALPHABET: gap, stop, mask, start, pad) does not match the alphabet the checkpoint "
+            "was trained with; fix that table (or the checkpoint is not an EvoDiff sequence model)."
+            % (source, zero_rows, mask_id))
 
 
 def _d3pm(model_name, config, blosum, return_all, path_to_checkpoints, random_init):

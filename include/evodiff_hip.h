@@ -50,7 +50,9 @@ typedef struct ed_config {
   int32_t kernel_size;  /* 5 */
   int32_t r;            /* 128: dilation of layer n is 2**(n % (log2(r)+1)) (model.py:108-109) */
   int32_t timesteps;    /* 0 = no timestep encoding (OA-DM); 500 for D3PM (model.py:93-94,133) */
-  int32_t activation;   /* 1 = exact-erf GELU (the only activation on this path), 0 = ReLU */
+  int32_t activation;   /* 1 = GELU (the only activation on this path), 0 = ReLU.  ED_PREC_FP32 evaluates the exact-erf
+                           GELU (erff); ED_PREC_BF16 evaluates x * sigmoid(x (a + b x^2 + c x^4)), a fit of the exact-erf
+                           GELU with at most 2.6e-5 absolute error, ahead of the rounding to bf16 (2^-9 relative) */
   int32_t causal;       /* 0 = MaskedConv1d ('same' padding); 1 = MaskedCausalConv1d, (k-1)*dilation zeros in front
                            only (ByteNetBlock(causal=True), model.py:114: the LR_AR_* models) */
 } ed_config;
@@ -90,7 +92,11 @@ int64_t ed_model_num_params(const ed_model* m);
 
 /* Replaces: ByteNetLMTime.forward(x, y, input_mask=None) (evodiff/model.py:170-173).
  * tokens_dev int64 (B, L); timesteps_dev int64 (B,) (ignored when cfg.timesteps == 0);
- * logits_dev fp32 (B, L, n_tokens). */
+ * logits_dev fp32 (B, L, n_tokens).
+ * Token ids and timesteps are NOT validated by the C ABI (that would need a device-to-host copy per call): an id
+ * outside [0, n_tokens) is embedded as id n_tokens-1 and a timestep outside [0, timesteps) is clamped into it, so a
+ * kernel never indexes outside a table.  The Python layer (evodiff_amd.model) checks the ranges and raises
+ * IndexError like nn.Embedding would. */
 int ed_forward(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
                float* logits_dev, int precision, void* stream);
 /* Debug/validation variant: additionally copies the residual stream after the embedding and after
@@ -142,7 +148,9 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
                    const float* uniforms_dev, int B, int L, int K, int t_start, int n_steps,
                    double* post_dev, int precision, int use_graph, void* stream);
 
-/* Execution options (no counterpart in the reference; neither changes what is computed).
+/* Execution options (no counterpart in the reference).  They select kernels and what is recomputed, never the
+ * function: with ED_PREC_FP32 the results are bit-identical under every setting; with ED_PREC_BF16 different settings
+ * select kernels with different (fixed) orders of rounding, and results agree within the bf16 tolerance.
  *   ED_OPT_PRUNE (default 1): ed_oadm_sample reads the network output at ONE position per step
  *     (generate.py:198), so the trailing blocks whose dilations double from 1 are evaluated only on
  *     the positions that output depends on ("dependency-cone pruning").  0 = every block

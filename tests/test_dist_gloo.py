@@ -44,3 +44,56 @@ def test_sequence_sharding_and_gather(tmp_path):
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _bench_line(*flags):
+    """One `python bench.py --dry-run ...` run as the driver would start it (no torchrun around it): the stand-in
+    sampler on the CPU, gloo between the ranks bench.py starts itself.  Returns the parsed JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", *flags], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout                   # rank 0 prints ONE line, whatever the number of ranks
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_and_world_size_independent_tokens():
+    """bench.py's own code path: `python bench.py --gpus 2` starts two ranks itself instead of
+    exiting, and orders / uniforms are seeded by global batch / sequence index, so the gathered tokens are identical at
+    world 1 and 2 - in the strong form also when the shard size (11 -> 6 + 5) is not a multiple of --batch (4), and in
+    the weak form for the same global batches."""
+    base = ["--batch", "4", "--seq-len", "16", "--warmup", "0"]
+    one = _bench_line("--gpus", "1", "--steps", "1", "--total-sequences", "11", *base)
+    two = _bench_line("--gpus", "2", "--steps", "1", "--total-sequences", "11", *base)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["scaling"] == two["scaling"] == "strong"
+    assert one["tokens_sha256"] == two["tokens_sha256"]
+    other = _bench_line("--gpus", "2", "--steps", "1", "--total-sequences", "12", *base)
+    assert other["tokens_sha256"] != one["tokens_sha256"]             # (the digest does see the tokens)
+    weak1 = _bench_line("--gpus", "1", "--steps", "2", *base)        # global batches 0 and 1, one after the other
+    weak2 = _bench_line("--gpus", "2", "--steps", "1", *base)        # global batches 0 and 1, side by side
+    assert weak2["n_gpus"] == 2 and weak2["config"]["global_batch"] == 8 and weak2["scaling"] == "weak"
+    assert weak1["tokens_sha256"] == weak2["tokens_sha256"]
+
+
+def test_global_sub_batch_grid_and_streams():
+    sys.path.insert(0, ROOT)
+    from evodiff_amd.parallel import batch_order, global_sub_batches, sequence_uniforms, shard_range
+    # a shard's pieces follow the global grid: never across a multiple of the batch, every sequence once
+    for n, w, bs in ((11, 2, 4), (4096, 8, 64), (10, 3, 4), (5, 4, 8)):
+        seen = []
+        for r in range(w):
+            lo, hi = shard_range(n, r, w)
+            for a, b, j in global_sub_batches(lo, hi, bs):
+                assert lo <= a < b <= hi and a // bs == j == (b - 1) // bs
+                seen.extend(range(a, b))
+        assert seen == list(range(n))
+    u = sequence_uniforms(7, 3, 9, (5,))
+    assert u.shape == (5, 6) and u.dtype == np.float32 and 0 <= u.min() and u.max() < 1
+    assert np.array_equal(u[:, 2:4], sequence_uniforms(7, 5, 7, (5,)))      # a sequence's stream ignores its neighbours
+    assert sorted(batch_order(1, 3, 16).tolist()) == list(range(16))
+    assert not np.array_equal(batch_order(1, 3, 16), batch_order(1, 4, 16))

@@ -93,6 +93,64 @@ def test_checkpoint_round_trip(tmp_path):
         del os.environ["EVODIFF_CHECKPOINT_DIR"]
 
 
+def test_loaded_checkpoint_alphabet_self_check(tmp_path):
+    """SURVEY §3.5 Q4 / §8f row 2 (pretrained.py:39-52): a checkpoint trained with padding_idx=mask_id has exactly one
+    all-zero embedding row, at mask_id.  A checkpoint whose zero row sits elsewhere (= another alphabet order) must be
+    refused with an error that names the alphabet table, not sampled from."""
+    from evodiff_amd import pretrained
+    cfg = os.path.join(ROOT, "evodiff_amd", "config", "config38M.json")
+    torch.manual_seed(5)
+    src, tok = pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, random_init=True)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    good = tmp_path / "good.tar"
+    torch.save({"model_state_dict": {"module." + k: v for k, v in sd.items()}}, good)
+    pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(good))     # passes
+    # the same weights as a model trained with mask at index 27 (STOP and MASK swapped in the alphabet)
+    emb = sd["embedder.embedder.weight"].clone()
+    emb[[27, 28]] = emb[[28, 27]]
+    bad = tmp_path / "bad.tar"
+    torch.save({"model_state_dict": {"module." + k: (emb if k == "embedder.embedder.weight" else v)
+                                     for k, v in sd.items()}}, bad)
+    with pytest.raises(ValueError, match=r"constants\.py.*MSA_ALPHABET"):
+        pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(bad))
+    # a checkpoint with no zero row at all (padding_idx never used) is refused too
+    emb = sd["embedder.embedder.weight"].clone()
+    emb[28] = 0.5
+    torch.save({"model_state_dict": {"module." + k: (emb if k == "embedder.embedder.weight" else v)
+                                     for k, v in sd.items()}}, bad)
+    with pytest.raises(ValueError, match="mask_id is 28"):
+        pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(bad))
+
+
+def test_ed_config_layout_agrees_everywhere():
+    """The struct the reference-side binding passes to ed_model_create must be the header's: the field list of
+    `ed_config` in include/evodiff_hip.h, of `_lib.EdConfig`, and of the `EdConfig` shown in INTEGRATION.md are one
+    list (a stale stub would make ed_model_create read past the caller's struct)."""
+    from evodiff_amd import _lib
+    header = open(os.path.join(ROOT, "include", "evodiff_hip.h")).read()
+    body = re.search(r"typedef struct ed_config \{(.*?)\} ed_config;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    in_header = re.findall(r"int32_t\s+(\w+)\s*;", body)
+    assert len(in_header) == body.count(";"), "ed_config holds a field that is not int32_t"
+    in_binding = [name for name, ctype in _lib.EdConfig._fields_]
+    assert all(ctype is ctypes.c_int32 for _, ctype in _lib.EdConfig._fields_)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = re.search(r"class EdConfig\(C\.Structure\):\s*_fields_ = \[\(n, C\.c_int32\) for n in \((.*?)\)\]", doc, re.S).group(1)
+    in_doc = re.findall(r'"(\w+)"', stub)
+    assert in_header == in_binding == in_doc, (in_header, in_binding, in_doc)
+    assert ctypes.sizeof(_lib.EdConfig) == 4 * len(in_header)
+
+
+def test_timestep_table_is_the_reference_table(golden_dir):
+    """PositionalEncoding1D.table() (model.py:26-33) bit for bit against the table the reference's own class built."""
+    from evodiff_amd.model import PositionalEncoding1D
+    g = np.load(os.path.join(golden_dir, "tiny_timeenc.npz"))
+    assert np.array_equal(PositionalEncoding1D(8, 500).table().numpy(), g["pe"])
+    assert np.array_equal(PositionalEncoding1D(8, 500)(torch.tensor([0, 499, 3])).numpy(), g["pe"][[0, 499, 3]])
+    with pytest.raises(ValueError):
+        PositionalEncoding1D(7, 10).table()
+
+
 def test_tokenizer_and_schedules_against_reference_golden(golden_dir):
     from evodiff_amd.utils import DEFAULT_BLOSUM, Tokenizer
     g = np.load(os.path.join(golden_dir, "schedules.npz"))
