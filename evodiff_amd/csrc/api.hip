@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <tuple>
@@ -1181,6 +1182,64 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   } else {
     LAUNCH_TRY(launch_gemm_generic(p, s));
   }
+  return ED_OK;
+}
+
+// ---- allocation-free entry point (no counterpart in the reference) --------------------------------------------------
+// The split-K form of ed_debug_gemm (kernel = 100 / 200 + ksplit) keeps its partial sums in a library-allocated buffer.
+// Callers that cannot call hipMalloc (under hipGraph capture, tight serving loops) get the same computation with the
+// partial sums in a file-scope device array instead: ED_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.
+// `scratch` is a host-side stand-in for the array, not a device address: host code only ever uses the per-device
+// pointer hipGetSymbolAddress returns (each GPU has its own copy of the array at its own address).
+static __device__ __align__(256) unsigned char scratch[ED_NOALLOC_SCRATCH_BYTES];
+constexpr int ED_MAX_DEVICES = 64;
+static float* g_scratch_ptr[ED_MAX_DEVICES] = {nullptr};  // device address of `scratch`, per device (set once)
+static std::mutex g_scratch_mu;
+
+// Device address of this device's copy of `scratch`; looked up once per device, with that device current.
+static int scratch_for_current_device(float** out) {
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= ED_MAX_DEVICES) return fail(ED_EINVAL, "device %d is outside the table of %d devices", dev, ED_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p)
+      return fail(ED_EHIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return ED_OK;
+}
+
+int ed_debug_gemm_splitk_noalloc(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const void* W_dev,
+                                 const float* bias_dev, void* out_dev, const float* resid_dev, int B, int L, int N, int K,
+                                 int ntaps, int dilation, int out_bf16, int tile, int ksplit, void* stream) {
+  if (!A_dev || !W_dev || !bias_dev || !out_dev) return fail(ED_EINVAL, "null pointer");
+  if (B <= 0 || L <= 0 || N <= 0 || K <= 0 || ntaps < 1 || !(ntaps & 1) || dilation < 1)
+    return fail(ED_EINVAL, "bad GEMM shape");
+  if (resid_dev && out_bf16) return fail(ED_EINVAL, "a residual add requires fp32 output");
+  if (K % 32) return fail(ED_EINVAL, "K must be a multiple of 32 (bf16 operands)");
+  if (N % 4) return fail(ED_EINVAL, "N must be a multiple of 4");
+  if (tile != 64 && tile != 128) return fail(ED_EINVAL, "tile must be 64 or 128");
+  if (ksplit < 2 || ksplit > 16) return fail(ED_EINVAL, "ksplit must be in [2, 16]");
+  const unsigned long long need = 4ull * (unsigned long long)ksplit * (unsigned long long)B * (unsigned long long)L * (unsigned long long)N;
+  if (need > ED_NOALLOC_SCRATCH_BYTES)
+    return fail(ED_EINVAL, "ksplit * B * L * N * 4 = %llu bytes of partial sums exceed the %llu-byte static scratch "
+                           "(ED_NOALLOC_SCRATCH_BYTES); use ed_debug_gemm, which allocates", need,
+                (unsigned long long)ED_NOALLOC_SCRATCH_BYTES);
+  float* ptr = nullptr;
+  int rc = scratch_for_current_device(&ptr);
+  if (rc) return rc;
+  GemmProblem p{A_dev, (long)a_seq_pitch, (long)a_row0, W_dev, bias_dev, out_dev, resid_dev, B, L, N, K, ntaps,
+                dilation, true, out_bf16 != 0};
+  p.tile = tile;
+  p.ksplit = ksplit;
+  p.partial = ptr;  // every range z stores every element of its slab (zeros for an empty range): nothing to clear
+  hipStream_t s = (hipStream_t)stream;
+  LAUNCH_TRY(launch_gemm_generic(p, s));
+  LAUNCH_TRY(launch_reduce_partials(p, s));
   return ED_OK;
 }
 

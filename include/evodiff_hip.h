@@ -194,6 +194,21 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
                   void* out_dev, const float* resid_dev, int B, int L, int N, int K, int ntaps, int dilation,
                   int a_bf16, int out_bf16, int kernel, void* stream);
 
+/* Allocation-free variant of ed_debug_gemm(kernel = 100 + ksplit / 200 + ksplit): the small-tile kernel (tile = 128 or
+ * 64) with its K loop cut `ksplit` ways across workgroups, then the fixed-order reduction with bias (+ residual).
+ * It has NO counterpart in the reference; it exists for callers that cannot allocate - code under hipGraph capture,
+ * tight serving loops, harnesses that forbid hipMalloc: where ed_debug_gemm keeps the partial sums in a buffer it
+ * allocates, this entry point keeps them in a static device array of ED_NOALLOC_SCRATCH_BYTES (each GPU the library
+ * runs on holds its own copy until the process ends) and calls no hipMalloc / hipFree or other allocating routine.
+ * bf16 operands only (A, W bf16; out fp32 or bf16); same argument meaning and the same results, bit for bit, as
+ * ed_debug_gemm.  ED_EINVAL when ksplit * B * L * N * 4 exceeds ED_NOALLOC_SCRATCH_BYTES, or ksplit is outside
+ * [2, 16].  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * serialise them.  The device must be current (hipSetDevice) as for ed_debug_gemm. */
+#define ED_NOALLOC_SCRATCH_BYTES (16u << 20)
+int ed_debug_gemm_splitk_noalloc(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const void* W_dev,
+                                 const float* bias_dev, void* out_dev, const float* resid_dev, int B, int L, int N, int K,
+                                 int ntaps, int dilation, int out_bf16, int tile, int ksplit, void* stream);
+
 /* Diagnostic hook for ed_debug_gemm(kernel = 9): a device buffer of n int64 that receives, per 256-row tile of the
  * tuned kernels, {prologue, K loop, epilogue} shader cycles and the 100-MHz ticks they span (the windowed convolution
  * stamps its K loop only: {0, loop cycles, 0, loop ticks}).  NULL detaches the buffer. */
