@@ -119,6 +119,14 @@ struct ed_model {
   // never change), a step computes one new row per sequence and layer.  Car[k]: [B][conv_pitch][d_hidden].
   std::vector<DevBuf> Car;
   int ar_B = 0, ar_L = 0, ar_prec = -1;
+  // LayerNorm fused into the tuned kernels' epilogues (ED_OPT_FUSE_LN, ln_epilogue.hpp): exchange buffer for the per-row
+  // partial statistics, arrival counters (one array per GEMM of the block: a counter must always see the same number of
+  // column tiles), and a host-visible error word the kernels raise when a bounded wait runs out.
+  bool fuse_ln = true;
+  DevBuf Abuf1, ln_stats, ln_counters;
+  long ln_counter_pitch = 0;
+  unsigned* ln_err_host = nullptr;
+  unsigned* ln_err_dev = nullptr;
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 1024;     // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   int tuned_split_min_rows = 0;  // ED_OPT_TUNED_SPLIT_MIN_ROWS: problems of at least this many rows that are too small for the
@@ -147,6 +155,7 @@ struct ed_model {
     for (auto& e : event_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (ln_err_host) (void)hipHostFree(ln_err_host);
   }
   void drop_graphs() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
@@ -324,6 +333,37 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s, GemmPro
   return ED_OK;
 }
 
+// The LayerNorm + GELU behind GEMM `p` (kind 0 PFF1, 1 convolution, 2 PFF2) applied in p's own epilogue, when p runs on
+// the tuned kernels and they can (ln_epilogue.hpp): fills p.ln and returns true; the caller then skips that LayerNorm.
+// Flat GEMM row R goes to row R of `out`, or with seq_len > 0 to row (R / seq_len) * pitch + row0 + R % seq_len.
+bool fuse_ln_into(ed_model* m, GemmProblem& p, int kind, const float* gamma, const float* beta, void* out, int seq_len,
+                  long pitch, long row0) {
+  if (!m->fuse_ln || m->cfg.activation != 1 || !p.a_bf16 || !m->ln_stats.p || !m->ln_err_dev) return false;
+  if (!use_tuned_gemm(m, p) || !gemm_bf16_ln_supported(p)) return false;
+  const long row_tiles = (long)p.B * ((p.L + 127) / 128);
+  if (row_tiles > m->ln_counter_pitch) return false;
+  p.ln.gamma = gamma;
+  p.ln.beta = beta;
+  p.ln.out = (bf16_t*)out;
+  p.ln.seq_len = seq_len;
+  p.ln.out_pitch = pitch;
+  p.ln.out_row0 = row0;
+  p.ln.stats = m->ln_stats.p;
+  p.ln.counters = m->ln_counters.as<unsigned>() + (long)kind * m->ln_counter_pitch;
+  p.ln.error = m->ln_err_dev;
+  return true;
+}
+
+// Errors the kernels could only report asynchronously (a bounded inter-workgroup wait that ran out).
+int check_async_errors(ed_model* m) {
+  if (m->ln_err_host && *(volatile unsigned*)m->ln_err_host) {
+    *(volatile unsigned*)m->ln_err_host = 0;
+    return fail(ED_EHIP, "a fused-LayerNorm kernel gave up waiting for the other workgroups of its row tile in an earlier "
+                         "launch (results of that call are invalid); ed_model_set_option(ED_OPT_FUSE_LN, 0) avoids the exchange");
+  }
+  return ED_OK;
+}
+
 int run_ln(ed_model* m, const void* in, bool in_bf16, void* out, bool out_bf16, const float* g, const float* b,
            int rows, int C, const LnRowMap& map, int act, hipStream_t s) {
   Probe pr(m, s);
@@ -408,6 +448,24 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   if (prelayout && m->Cprune.p) HIP_TRY(hipMemsetAsync(m->Cprune.p, 0, m->Cprune.bytes, s));
   if (m->plan_s_final > 1) HIP_TRY(need(m->X2, ((size_t)B * L / 2 + 256) * c.d_model * 4));
   HIP_TRY(need(m->partials, (size_t)m->partials_mb << 20));
+  {
+    HIP_TRY(need(m->Abuf1, rows * Cmax * 4));
+    // fused LayerNorm exchange: a row tile is 128 or 256 rows of ONE sequence, a column tile at least 256 channels
+    const size_t tile_rows = (size_t)B * ((L + 127) / 128) * 128 + 256;
+    const size_t max_tn = std::max<size_t>(1, Cmax / 256);
+    HIP_TRY(need(m->ln_stats, tile_rows * max_tn * 8));
+    const size_t n_ctr = (tile_rows / 128 + 3) & ~(size_t)3;     // counters per GEMM kind, a multiple of 16 bytes
+    if (3 * n_ctr * 4 > m->ln_counters.bytes) {
+      HIP_TRY(need(m->ln_counters, 3 * n_ctr * 4));
+      HIP_TRY(hipMemsetAsync(m->ln_counters.p, 0, m->ln_counters.bytes, s));  // zero once; launches keep them consistent
+    }
+    m->ln_counter_pitch = (long)(m->ln_counters.bytes / 12);
+    if (!m->ln_err_host) {
+      HIP_TRY(hipHostMalloc((void**)&m->ln_err_host, 64, hipHostMallocMapped));
+      *m->ln_err_host = 0;
+      HIP_TRY(hipHostGetDevicePointer((void**)&m->ln_err_dev, m->ln_err_host, 0));
+    }
+  }
   // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
   m->n_inc = 0;
   if (m->incremental && c.timesteps == 0 && !c.causal) {
@@ -505,7 +563,9 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
   const int n_inc = variant == STEP_PLAIN ? 0 : m->n_inc;
   float* Xc = m->X.as<float>();
   float* Xo = m->X2.as<float>();
-  void* A = m->Abuf.p;
+  void* A = m->Abuf.p;    // LayerNorm 3 -> PFF2
+  void* A1 = m->Abuf1.p;  // LayerNorm 1 -> PFF1 (its own buffer: a PFF2 that applies the next block's LayerNorm 1 in its
+                          // epilogue writes it while other workgroups of the launch still read A)
   void* Y = m->Ybuf.p;
   // GEMM1 / conv results feed a LayerNorm straight away; in the fast path they are stored as bf16 (the
   // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
@@ -533,20 +593,24 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       x_src = m->Xc[i].as<float>();
     }
     // the 1x1 projections are row-independent: tile them over all rows as one long sequence
-    if (!ln1_done && (rc = run_ln(m, x_src, false, A, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+    if (!ln1_done && (rc = run_ln(m, x_src, false, A1, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
     ln1_done = false;
-    GemmProblem g1{A, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
+    GemmProblem g1{A1, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
     GemmProblem dq{};
-    if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s, &dq))) return rc;
     long y_pitch;  // rows per sequence of the convolution result in Y
+    bool ln3_fused = false;
     if (pl.s_in == 1) {
-      // every position: per-sequence zero halo in Cpad
+      // every position: per-sequence zero halo in Cpad.  Where the tuned kernels run, each GEMM applies the LayerNorm
+      // that follows it in its own epilogue (ln_epilogue.hpp) and the stand-alone launch is skipped.
       const LnRowMap to_pad{L, L, 0, 1, PosBit{}, m->conv_pitch, m->conv_row0, PosBit{}};
-      if ((rc = run_ln_after(m, dq, Y, y_bf16, cpad, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
+      const bool ln2_fused = fuse_ln_into(m, g1, 0, w.ln2_g, w.ln2_b, cpad, L, m->conv_pitch, m->conv_row0);
+      if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s, ln2_fused ? nullptr : &dq))) return rc;
+      if (!ln2_fused && (rc = run_ln_after(m, dq, Y, y_bf16, cpad, h, w.ln2_g, w.ln2_b, rows_in, H, to_pad, act, s))) return rc;
       GemmProblem gc{cpad, m->conv_pitch, m->conv_row0, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y,
                      nullptr, B, L, H, H, c.kernel_size, w.dilation, h, y_bf16};
       gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
-      if ((rc = run_gemm(m, gc, ED_K_CONV, s, &dq))) return rc;
+      ln3_fused = in_mul == 1 && fuse_ln_into(m, gc, 1, w.ln3_g, w.ln3_b, A, 0, 0, 0);
+      if ((rc = run_gemm(m, gc, ED_K_CONV, s, ln3_fused ? nullptr : &dq))) return rc;
       y_pitch = L;
     } else {
       // compact position set: neighbours at +-d are dc = d / s_in rows apart; the sequences sit back to back with
@@ -555,7 +619,9 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       const long gap = (long)half * dc, pitch = M_in + gap;
       char* Cc = (char*)m->Cprune.p + (size_t)pl.cp_row * H * esz;
       const LnRowMap to_compact{M_in, M_in, 0, 1, PosBit{}, pitch, gap, PosBit{}};
-      if ((rc = run_ln_after(m, dq, Y, y_bf16, Cc, h, w.ln2_g, w.ln2_b, rows_in, H, to_compact, act, s))) return rc;
+      const bool ln2_fused = fuse_ln_into(m, g1, 0, w.ln2_g, w.ln2_b, Cc, M_in, pitch, gap);
+      if ((rc = run_gemm(m, g1, ED_K_GEMM1X1, s, ln2_fused ? nullptr : &dq))) return rc;
+      if (!ln2_fused && (rc = run_ln_after(m, dq, Y, y_bf16, Cc, h, w.ln2_g, w.ln2_b, rows_in, H, to_compact, act, s))) return rc;
       GemmProblem gc{Cc, 0, gap, h ? (const void*)w.wc_h : (const void*)w.wc_f, w.bc, Y, nullptr,
                      1, (int)(B * pitch - gap), H, H, c.kernel_size, dc, h, y_bf16};
       if ((rc = run_gemm(m, gc, ED_K_CONV, s, &dq))) return rc;
@@ -570,7 +636,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       sel.mask = in_mul - 1;
     }
     const LnRowMap keep{M_out, y_pitch, 0, in_mul, sel, M_out, 0, PosBit{}};
-    if ((rc = run_ln_after(m, dq, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, keep, act, s))) return rc;
+    if (!ln3_fused && (rc = run_ln_after(m, dq, Y, y_bf16, A, h, w.ln3_g, w.ln3_b, rows_out, H, keep, act, s))) return rc;
     GemmProblem g2{A, rows_out, 0, h ? (const void*)w.w2_h : (const void*)w.w2_f, w.b2, x_dst, x_src, 1, rows_out, D, H, 1, 1, h, false};
     if (in_mul > 1) {
       g2.out = Xo;
@@ -578,13 +644,17 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       g2.resid_sel = sel;
       std::swap(Xc, Xo);
     }
-    // a split-K PFF2 leaves its reduction to the first LayerNorm of the next block (which also stores the new residual
-    // stream): that LayerNorm reads exactly the rows this block produced
+    // PFF2 is followed by the first LayerNorm of the next block, which reads exactly the rows this block produced:
+    // fused into PFF2's epilogue on the tuned kernels; a split-K PFF2 leaves its reduction to that LayerNorm (which
+    // also stores the new residual stream)
     GemmProblem dq2{};
-    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s, h && i + 1 < c.n_layers ? &dq2 : nullptr))) return rc;
+    const bool has_next = i + 1 < c.n_layers;
+    const bool ln1_fused = has_next && fuse_ln_into(m, g2, 2, m->layers[i + 1].ln1_g, m->layers[i + 1].ln1_b, A1, 0, 0, 0);
+    if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s, h && has_next && !ln1_fused ? &dq2 : nullptr))) return rc;
+    if (ln1_fused) ln1_done = true;
     if (dq2.ksplit > 1) {
       const LayerW& wn = m->layers[i + 1];
-      if ((rc = run_ln_after(m, dq2, nullptr, false, A, h, wn.ln1_g, wn.ln1_b, rows_out, D, LnRowMap::plain(rows_out), act, s))) return rc;
+      if ((rc = run_ln_after(m, dq2, nullptr, false, A1, h, wn.ln1_g, wn.ln1_b, rows_out, D, LnRowMap::plain(rows_out), act, s))) return rc;
       ln1_done = true;
     }
     if (acts)
@@ -945,6 +1015,7 @@ int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* ti
   if (m->cfg.timesteps > 0 && !timesteps_dev) return fail(ED_EINVAL, "timesteps_dev is required for a model with timestep encoding");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
+  if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   m->probing_now = m->probe_every > 0;
   rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, STEP_PLAIN, s);
@@ -987,6 +1058,7 @@ int ed_score_nll(ed_model* m, const int64_t* tokens_dev, const int64_t* timestep
       if ((!select_dev || sel[i]) && (tg[i] < 0 || tg[i] >= n_classes))
         return fail(ED_EINVAL, "targets[%zu] = %lld is outside [0, n_classes=%d)", i, (long long)tg[i], n_classes);
   }
+  if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   m->probing_now = m->probe_every > 0;
   rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, STEP_PLAIN, s);
@@ -1011,6 +1083,7 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
   if (n_draw < 1 || n_draw > m->cfg.n_tokens) return fail(ED_EINVAL, "n_draw must be in [1, n_tokens]");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
+  if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
   // positions are validated on the host before any kernel indexes with them
@@ -1048,6 +1121,7 @@ int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, in
   HIP_TRY(hipSetDevice(m->device));
   // the shared workspace only has to hold one row per sequence here, but its convolution layout (pitch, halo) is the
   // one the caches use: size it for (B, L) like any other call
+  if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
   {
@@ -1095,6 +1169,7 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
   if (n_steps < 0 || n_steps > t_start) return fail(ED_EINVAL, "n_steps must be in [0, t_start] (t runs down to 1)");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
+  if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
   // x_t indexes Q's columns: validate the token range on the host first
@@ -1288,6 +1363,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
       m->partials_mb = value;
       m->ws_B = m->ws_L = 0;
       break;
+    case ED_OPT_FUSE_LN:
+      if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_LN takes 0 or 1");
+      m->fuse_ln = value != 0;
+      break;
     case ED_OPT_SPLIT_MIN_ITERS:
       if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");
       m->split_min_iters = value;
@@ -1311,6 +1390,7 @@ int ed_probe_read(ed_model* m, ed_probe_stat* stats, void* stream) {
   if (!m || !stats) return fail(ED_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (int rc = check_async_errors(m)) return rc;
   for (int k = 0; k < ED_K_COUNT; ++k) stats[k] = ed_probe_stat{0.0, 0.0, 0.0, 0};
   for (auto& p : m->pending) {
     float ms = 0.f;

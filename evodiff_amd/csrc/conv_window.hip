@@ -24,6 +24,7 @@
 // tile can reach leave the K loop, and a wave skips a tap that moves all of its 64 rows into the padding (it still
 // issues its share of the copies); its SIMD partner then has the matrix pipe to itself.  See window_plan().
 #include "kernels.hpp"
+#include "ln_epilogue.hpp"
 
 #include <type_traits>
 
@@ -57,7 +58,9 @@ struct WindowPlan {
 // STAMP: diagnostic build that also records the K loop's duration (GemmProblem::stamps).
 // WM: waves along M, as in gemm_bf16.hip: 4 = 256-row tile, 2 = 128-row tile (4 waves) for launches that would
 // leave half of the CUs without a 256-row tile.
-template <int NT, bool OUT_BF16, bool STAMP = false, int WM = 4>
+// LNF: the LayerNorm + GELU behind the convolution (g.ln) is applied in the epilogue (ln_epilogue.hpp) and only the
+// normalised rows are stored.
+template <int NT, bool OUT_BF16, bool STAMP = false, int WM = 4, bool LNF = false>
 __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total,
                                                                WindowPlan wp) {
   constexpr int BM = WM * 64;      // tile rows
@@ -234,6 +237,12 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
   // through an empty asm so that the addresses are computed here and not kept live across the K loop.
   int l0e = l0;
   asm volatile("" : "+s"(l0e));
+  if constexpr (LNF) {
+    const unsigned ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, wr, wc, lane, tid);
+    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0, wr,
+                      wc, lane, tid);
+    return;
+  }
 #pragma unroll
   for (int ip = 0; ip < 4; ++ip) {
     const int l = l0e + wr * 64 + ip * 16 + fr;
@@ -304,11 +313,16 @@ hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream) {
   WindowPlan wp;
   const int wm = window_wm(p, &wp);
   if (!wm) return hipErrorInvalidValue;
+  if (p.ln.gamma && (!gemm_bf16_ln_supported(p) || !p.ln.beta || !p.ln.out || !p.ln.stats || !p.ln.counters || !p.ln.error))
+    return hipErrorInvalidValue;
 #define ED_GO(NTV, OB, WMV)                                                                               \
   {                                                                                                       \
     const int tiles_n = p.N / (NTV * 64);                                                                 \
     const int tiles_total = p.B * ((p.L + WMV * 64 - 1) / (WMV * 64)) * tiles_n;                          \
-    if (p.ablate == 7 && p.stamps)                                                                        \
+    if (p.ln.gamma)                                                                                       \
+      hipLaunchKernelGGL((conv_window_kernel<NTV, true, false, WMV, true>), dim3(tiles_total), dim3(WMV * 128), 0, \
+                         stream, p, tiles_n, tiles_total, wp);                                            \
+    else if (p.ablate == 7 && p.stamps)                                                                   \
       hipLaunchKernelGGL((conv_window_kernel<NTV, OB, true, WMV>), dim3(tiles_total), dim3(WMV * 128), 0, \
                          stream, p, tiles_n, tiles_total, wp);                                            \
     else                                                                                                  \

@@ -27,6 +27,7 @@
 // so a shifted tile is a plain contiguous row range and 'same' padding costs no bounds logic.  Taps whose
 // whole 256-row tile lies outside [0, L) are dropped from the K loop (at L = 256, dilation 128: 2 of 5 taps).
 #include "kernels.hpp"
+#include "ln_epilogue.hpp"
 
 namespace ed {
 
@@ -51,9 +52,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // SPLIT: the K loop of a tile is cut into g.ksplit ranges (blockIdx.y); range z accumulates from zero and stores raw
 // fp32 sums to g.partial[z] (bias, residual and rounding happen where the ranges are added up: launch_reduce_partials
 // or the LayerNorm behind the GEMM).  For problems with too few tiles to fill the chip.
-template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0, int WM = 4, bool SPLIT = false>
+// LNF: the LayerNorm + GELU behind this GEMM (g.ln) is applied in the epilogue (ln_epilogue.hpp); the raw result is
+// stored only in the residual form (PFF2: it is the residual stream).
+template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0, int WM = 4, bool SPLIT = false,
+          bool LNF = false>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
   static_assert(!SPLIT || (!OUT_BF16 && !RESID && RT == 0 && ABLATE == 0), "split form: raw fp32 partial sums only");
+  static_assert(!LNF || (!SPLIT && ABLATE == 0), "fused LayerNorm: whole sums only");
   constexpr int BM = WM * 64;       // (shadows the file-scope 256)
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
@@ -279,6 +284,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   // shared with the residual loads) they cost live registers.
   int l0e = l0;
   asm volatile("" : "+s"(l0e));
+  unsigned ln_target = 0;
+  if constexpr (LNF) ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, wr, wc, lane, tid);
+  if constexpr (!LNF || RESID) {
 #pragma unroll
   for (int ip = 0; ip < 4; ++ip) {
     const int l = l0e + wr * 64 + ip * 16 + fr;
@@ -302,6 +310,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
       }
     }
   }
+  }
+  if constexpr (LNF)
+    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0, wr,
+                      wc, lane, tid);
   if constexpr (ABLATE == 3) {  // diagnostic build: {prologue, K loop, epilogue incl. store drain} cycles, total ticks
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long sc3 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
@@ -320,6 +332,26 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   const int tiles_n = p.N / (NT * 64);
   const int tiles_total = p.B * ((p.L + BMT - 1) / BMT) * tiles_n;
   const dim3 grid(tiles_total), block(WM * 128);
+  if (p.ln.gamma) {  // LayerNorm + GELU in the epilogue
+    if (!gemm_bf16_ln_supported(p) || !p.ln.beta || !p.ln.out || !p.ln.stats || !p.ln.counters || !p.ln.error)
+      return hipErrorInvalidValue;
+    if (p.resid) {
+      if constexpr (!CONV) {
+        const bool whole = ((long)p.B * p.L) % BMT == 0 && (p.B == 1 || p.L % BMT == 0) && p.resid_mul == 1;
+        if (whole && p.K == 20 * BK)
+          hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 20, WM, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+        else if (whole && NT == 4 && p.K == 8 * BK)
+          hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 8, WM, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+        else
+          hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 0, 0, WM, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+      } else {
+        return hipErrorInvalidValue;
+      }
+    } else {
+      hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, true, false, 0, 0, WM, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+    }
+    return hipGetLastError();
+  }
   if (p.ksplit > 1) {  // K loop cut across workgroups: raw partial sums
     if (!p.partial || p.ablate != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, false, 0, 0, WM, true>), dim3(tiles_total, p.ksplit), block, 0,

@@ -49,6 +49,20 @@ struct PosBit {
   }
 };
 
+// LayerNorm + GELU of a GEMM's result fused into the tuned kernels' epilogue (ln_epilogue.hpp).  gamma == nullptr: off.
+struct LnFuse {
+  const float* gamma = nullptr;  // [N] of the LayerNorm that consumes this GEMM's result
+  const float* beta = nullptr;
+  bf16_t* out = nullptr;         // GELU(LayerNorm(result)) as bf16 rows of N channels; flat GEMM row R goes to row R, or with
+  int seq_len = 0;               //   seq_len > 0 to row (R / seq_len) * out_pitch + out_row0 + R % seq_len (padded conv input)
+  long out_pitch = 0, out_row0 = 0;
+  void* stats = nullptr;         // exchange buffer: 8 bytes per (row tile, column tile, tile row)
+  unsigned* counters = nullptr;  // one arrival counter per row tile; never reset (see ln_epilogue.hpp)
+  unsigned* error = nullptr;     // host-visible word, set to 1 when a bounded wait ran out
+  // The GEMM's own result is still stored to GemmProblem::out when it has a residual (PFF2: the fp32 residual stream);
+  // otherwise only the normalised rows leave the kernel.
+};
+
 // One implicit-GEMM problem: out[b*L + l][n] = bias[n] (+ resid) + sum_{tap,k} A[row(b, l + off(tap))][k] * W[tap][n][k]
 // with off(tap) = (tap - ntaps/2) * dilation and rows outside [0, L) contributing zero.
 struct GemmProblem {
@@ -80,6 +94,7 @@ struct GemmProblem {
   int ablate = 0;       // diagnostics of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong), 3 = no window form
   int tap_center = -1;  // tap t reads position l + (t - center) * dilation; -1 = ntaps / 2 ('same' padding, MaskedConv1d),
                         //   ntaps - 1 = causal (left padding only, MaskedCausalConv1d)
+  LnFuse ln;            // tuned kernels only: the LayerNorm behind this GEMM, applied in its epilogue
   __host__ __device__ int center() const { return tap_center >= 0 ? tap_center : ntaps / 2; }
 };
 
@@ -98,6 +113,12 @@ inline int gemm_bf16_tile_rows(const GemmProblem& p) {
   return p.ablate == 0 && gemm_bf16_full_tiles(p) <= 128 ? 128 : 256;
 }
 hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream);
+// Whether the tuned kernels can apply p.ln themselves: the column tiles of a row tile must be a power of two (see
+// ln_epilogue.hpp), no cut K loop, no diagnostic form.  The caller decides on the activation (GELU only).
+inline bool gemm_bf16_ln_supported(const GemmProblem& p) {
+  const int tn = p.N % 320 == 0 ? p.N / 320 : p.N / 256;
+  return gemm_bf16_supported(p) && p.ksplit == 1 && p.ablate == 0 && tn >= 1 && (tn & (tn - 1)) == 0;
+}
 // Window-in-LDS form of the dilated convolution (conv_window.hip): five taps, dilation <= 16; launch_gemm_bf16
 // picks it by itself when the shape allows (GemmProblem::ablate == 3 keeps the per-tap form, for comparisons).
 bool conv_window_supported(const GemmProblem& p);

@@ -171,10 +171,15 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
  *     64 x 64 tiles (four times the workgroups before any K loop is cut); 0 = never.
  *   ED_OPT_TUNED_SPLIT_MIN_ROWS (default 0): bf16 GEMMs of at least this many rows with fewer tuned tiles than
  *     ED_OPT_MIN_TUNED_TILES run the tuned kernel (128-row tiles) with its K loop cut across workgroups; 0 = never.
- *   ED_OPT_PARTIALS_MB (default 32): size in MiB of the partial-sum workspace (a cut needs ksplit x rows x N x 4 B). */
+ *   ED_OPT_PARTIALS_MB (default 32): size in MiB of the partial-sum workspace (a cut needs ksplit x rows x N x 4 B).
+ *   ED_OPT_FUSE_LN (default 1): bf16 GEMMs on the tuned kernels apply the LayerNorm + GELU that follows them (PFF1 -> LN2,
+ *     convolution -> LN3, PFF2 -> LN1 of the next block) in their own epilogue - the column tiles of a row tile exchange
+ *     per-row partial statistics inside the launch - instead of a separate LayerNorm launch; the statistics are then
+ *     taken on the fp32 sums rather than on their bf16 roundings.  0 = separate launches.  If a workgroup ever gives up
+ *     waiting for its partners (bounded wait), the NEXT call on the model returns ED_EHIP. */
 enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1, ED_OPT_SPLIT_TARGET = 2, ED_OPT_INCREMENTAL = 3,
        ED_OPT_FUSE_REDUCE_LN = 4, ED_OPT_SPLIT_MIN_ITERS = 5, ED_OPT_PARTIALS_MB = 6, ED_OPT_TILE64_MAX = 7,
-       ED_OPT_TUNED_SPLIT_MIN_ROWS = 8 };
+       ED_OPT_TUNED_SPLIT_MIN_ROWS = 8, ED_OPT_FUSE_LN = 9 };
 int ed_model_set_option(ed_model* m, int option, int value);
 
 /* Measurement hooks (no counterpart in the reference).  With a probe interval n > 0, every n-th

@@ -753,3 +753,42 @@ def test_autoregressive_sampler_vs_oracle(dev, base, precision, max_len):
     with pytest.raises(Exception, match="causal"):
         product_model(R.build_model(dict(base, n_tokens=30), None, 41), dict(base, n_tokens=30)).ar_sample(
             again, uni.t().contiguous().to(dev), n_steps=max_len)
+
+
+@pytest.mark.parametrize("cfg,B,L", [(BIG640, 4, 512), (BIG640, 16, 130), (BIG640, 64, 256), (BIG512, 9, 300),
+                                     (BIG512, 3, 256), (BIG640, 1, 1024), (BIG640, 5, 77)])
+def test_layernorm_in_gemm_epilogue_matches_separate_launches(dev, cfg, B, L):
+    """ED_OPT_FUSE_LN: on the tuned kernels every GEMM of a block applies the LayerNorm + GELU behind it in its own
+    epilogue (the column tiles of a row tile exchange per-row statistics inside the launch).  Against separate
+    LayerNorm launches only the rounding differs (statistics on the fp32 sums instead of their bf16 roundings): logits
+    agree far inside the bf16 tolerance, both stay within it of the oracle, and repeated launches are bit-identical
+    (fixed order of every reduction, whichever workgroup arrives first).  Shapes: full and ragged row tiles, 128- and
+    256-row tiles, one and two column tiles per row tile, the per-tap convolution form (L > 256, dilation >= 32)."""
+    oracle = R.build_model(cfg, None, 21)
+    m = product_model(oracle, cfg, precision="bf16")
+    m.set_option("min_tuned_tiles", 0)            # tuned kernels wherever the shape allows
+    x = torch.from_numpy(np.random.default_rng(B * 1000 + L).integers(0, 31, (B, L)))
+    with torch.no_grad():
+        ref = oracle(x, torch.zeros(B, dtype=torch.long)).numpy()
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    m.set_option("fuse_ln", 0)
+    apart = m(x.to(dev), t).cpu().numpy()
+    m.set_option("fuse_ln", 1)
+    fused = m(x.to(dev), t).cpu().numpy()
+    assert rel_err(apart, ref) < BF16_TOL and rel_err(fused, ref) < BF16_TOL
+    assert rel_err(fused, apart) < 1e-2
+    for _ in range(3):
+        assert np.array_equal(m(x.to(dev), t).cpu().numpy(), fused)
+    # a free-running pruned + incremental sampling loop under graph replay: many back-to-back launches on the same
+    # arrival counters, eager and replayed launches bit-identical
+    n = min(L, 16)
+    order = torch.from_numpy(np.random.default_rng(L).permutation(L)[:n].astype(np.int32))
+    uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32)).to(dev)
+    outs = []
+    for use_graph in (True, False, True):
+        m.use_graph = use_graph
+        sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+        m.oadm_sample(sample, order, uni, R.OADM_DRAW)
+        outs.append(sample.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert (outs[0][:, order.numpy()] < R.OADM_DRAW).all()
