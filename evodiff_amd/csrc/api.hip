@@ -1229,7 +1229,38 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
       p.stamps = g_stamp_buf;
     }
   }
-  if (kernel >= 300) {  // tuned kernel with its K loop cut kernel - 300 ways + the reduction
+  if (kernel >= 400) {  // tuned kernel with a LayerNorm + GELU (gamma = 1, beta = 0) in its epilogue; 400 + diagnostic bits
+    static DevBuf dbg_ln_out, dbg_ln_stats, dbg_ln_ctr, dbg_ln_vec;
+    static unsigned* dbg_err_host = nullptr;
+    static unsigned* dbg_err_dev = nullptr;
+    if (!gemm_bf16_ln_supported(p)) return fail(ED_EINVAL, "kernel 400+: shape outside the fused-LayerNorm contract");
+    const size_t rows = (size_t)B * ((L + 127) / 128) * 128 + 256;
+    HIP_TRY(dbg_ln_out.ensure(rows * N * 2));
+    HIP_TRY(dbg_ln_stats.ensure(rows * 8 * 8));
+    if (dbg_ln_ctr.bytes < rows / 128 * 4) {
+      HIP_TRY(dbg_ln_ctr.ensure(rows / 128 * 4));
+      HIP_TRY(hipMemsetAsync(dbg_ln_ctr.p, 0, dbg_ln_ctr.bytes, s));
+    }
+    if (dbg_ln_vec.bytes < (size_t)N * 8) {
+      HIP_TRY(dbg_ln_vec.ensure((size_t)N * 8));
+      std::vector<float> gb((size_t)2 * N, 0.f);
+      std::fill(gb.begin(), gb.begin() + N, 1.f);
+      HIP_TRY(hipMemcpy(dbg_ln_vec.p, gb.data(), gb.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!dbg_err_host) {
+      HIP_TRY(hipHostMalloc((void**)&dbg_err_host, 64, hipHostMallocMapped));
+      *dbg_err_host = 0;
+      HIP_TRY(hipHostGetDevicePointer((void**)&dbg_err_dev, dbg_err_host, 0));
+    }
+    p.ln.gamma = dbg_ln_vec.as<float>();
+    p.ln.beta = dbg_ln_vec.as<float>() + N;
+    p.ln.out = dbg_ln_out.as<bf16_t>();
+    p.ln.stats = dbg_ln_stats.p;
+    p.ln.counters = dbg_ln_ctr.as<unsigned>();
+    p.ln.error = dbg_err_dev;
+    p.ln.dbg = kernel - 400;
+    LAUNCH_TRY(launch_gemm_bf16(p, s));
+  } else if (kernel >= 300) {  // tuned kernel with its K loop cut kernel - 300 ways + the reduction
     static DevBuf dbg_partials2;
     p.ksplit = kernel - 300;
     if (!gemm_bf16_supported(p) || p.ksplit < 2 || p.ksplit > 16) return fail(ED_EINVAL, "kernel 300 + ksplit: tuned shape, ksplit in [2, 16]");

@@ -238,9 +238,9 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
   int l0e = l0;
   asm volatile("" : "+s"(l0e));
   if constexpr (LNF) {
-    const unsigned ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, wr, wc, lane, tid);
-    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0, wr,
-                      wc, lane, tid);
+    const unsigned ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, (int)threadIdx.x);
+    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0,
+                      (int)threadIdx.x);
     return;
   }
 #pragma unroll

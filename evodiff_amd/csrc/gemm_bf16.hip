@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   int l0e = l0;
   asm volatile("" : "+s"(l0e));
   unsigned ln_target = 0;
-  if constexpr (LNF) ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, wr, wc, lane, tid);
+  if constexpr (LNF) ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, (int)threadIdx.x);
   if constexpr (!LNF || RESID) {
 #pragma unroll
   for (int ip = 0; ip < 4; ++ip) {
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   }
   }
   if constexpr (LNF)
-    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0, wr,
-                      wc, lane, tid);
+    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0,
+                      (int)threadIdx.x);
   if constexpr (ABLATE == 3) {  // diagnostic build: {prologue, K loop, epilogue incl. store drain} cycles, total ticks
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long sc3 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();

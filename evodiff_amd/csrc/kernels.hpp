@@ -59,6 +59,8 @@ struct LnFuse {
   void* stats = nullptr;         // exchange buffer: 8 bytes per (row tile, column tile, tile row)
   unsigned* counters = nullptr;  // one arrival counter per row tile; never reset (see ln_epilogue.hpp)
   unsigned* error = nullptr;     // host-visible word, set to 1 when a bounded wait ran out
+  int dbg = 0;                   // diagnostics (ed_debug_gemm 400 + dbg; results invalid): 1 no wait for the partners, 2 no GELU,
+                                 //   4 no stores of the normalised rows, 8 no statistics pass
   // The GEMM's own result is still stored to GemmProblem::out when it has a residual (PFF2: the fp32 residual stream);
   // otherwise only the normalised rows leave the kernel.
 };

@@ -7,7 +7,7 @@
 // from the fp32 accumulators: the stand-alone LayerNorm launch, its kernel boundary and the round trip of the raw GEMM
 // result through memory disappear (and the statistics are taken on the fp32 sums, not on their bf16 roundings).
 //
-// Statistics.  Per row: a lane's 8 NT values give (mean, M2) about their own mean; the 8 lane partials of a row inside a
+// Statistics.  Per row: a lane's 8 NT values give (mean, M2 about that mean); the 8 lane partials of a row inside a
 // workgroup and then the tiles_n workgroup partials are merged with the equal-count form of Chan's update
 //   mean = avg(mean_i),  M2 = sum(M2_i) + n * sum((mean_i - mean)^2)
 // in a fixed order, so the result does not depend on timing, tile height or dispatch order.
@@ -67,27 +67,39 @@ __device__ __forceinline__ lnf32x2 ln_gelu2(lnf32x2 x) {
 // statistics, normalise + GELU + bf16 store.  `row_base` = flat row (b*L + l0) of the tile's first position.
 template <int NT, int WM, typename Acc>
 __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, char* lds, int tile_m, int tile_n,
-                                               int tiles_n, int wr, int wc, int lane, int tid) {
+                                               int tiles_n, int tid_in) {
   constexpr int BM = WM * 64, NJ = 2 * NT, NL = 4 * NJ;  // NL values per lane and position
   const LnFuse& f = g.ln;
+  // every lane-derived index is formed here, from one laundered register: nothing of the epilogue stays live across
+  // the K loop (the fully unrolled loops run at the register limit)
+  int tid = tid_in;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
   lnf32x2* const red = (lnf32x2*)lds;                 // [BM][8] lane partials {mean, M2}
 
   // ---- 1. lane partials
 #pragma unroll
   for (int ip = 0; ip < 4; ++ip) {
-    float s = 0.f;
+    if (f.dbg & 8) {
+      red[(wr * 64 + ip * 16 + fr) * 8 + wc * 4 + fq] = lnf32x2{0.f, 1.f};
+      continue;
+    }
+    // one pass, two elements per instruction (v_pk_add_f32 / v_pk_fma_f32): sum and sum of squares of the lane's NL
+    // values; M2 about the lane's own mean is q - s^2 / NL (a cancellation over NL = 32 / 40 values only: the merge
+    // of the partials below is the stable form)
+    lnf32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-    for (int jn = 0; jn < NJ; ++jn) s += (acc[jn][ip][0] + acc[jn][ip][1]) + (acc[jn][ip][2] + acc[jn][ip][3]);
-    const float m = s * (1.0f / NL);
-    float q = 0.f;
-#pragma unroll
-    for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = acc[jn][ip][e] - m;
-        q = fmaf(d, d, q);
-      }
+    for (int jn = 0; jn < NJ; ++jn) {
+      const lnf32x2 a = {acc[jn][ip][0], acc[jn][ip][1]}, c = {acc[jn][ip][2], acc[jn][ip][3]};
+      s2 += a;
+      q2 = __builtin_elementwise_fma(a, a, q2);
+      s2 += c;
+      q2 = __builtin_elementwise_fma(c, c, q2);
+    }
+    const float sl = s2.x + s2.y;
+    const float m = sl * (1.0f / NL);
+    const float q = fmaxf(fmaf(-sl, m, q2.x + q2.y), 0.f);
     red[(wr * 64 + ip * 16 + fr) * 8 + wc * 4 + fq] = lnf32x2{m, q};
   }
   __syncthreads();
@@ -125,15 +137,17 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
 
 template <int NT, int WM, typename Acc>
 __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* lds, unsigned target, int tile_m,
-                                          int tiles_n, long row_base, int rows_valid, int n0, int wr, int wc, int lane,
-                                          int tid) {
+                                          int tiles_n, long row_base, int rows_valid, int n0, int tid_in) {
   constexpr int BM = WM * 64, BN = NT * 64;
   const LnFuse& f = g.ln;
+  int tid = tid_in;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
   lnf32x2* const rowstat = (lnf32x2*)(lds + BM * 64);  // [BM] {mean, rstd}; behind ln_publish's [BM][8] partials
   ln_gu64* const slab = (ln_gu64*)f.stats + ((long)tile_m * tiles_n) * BM;
   // ---- wait for the other workgroups of the row tile (one lane polls, relaxed; bounded)
-  if (tid == 0 && tiles_n > 1) {
+  if (tid == 0 && tiles_n > 1 && !(f.dbg & 1)) {
     ln_gu32* const ctr = (ln_gu32*)f.counters + tile_m;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
@@ -196,9 +210,9 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         y[k] = __builtin_elementwise_fma(__builtin_elementwise_fma(y[k], (lnf32x2)(rs[ip]), (lnf32x2)(sh[ip])), gm[k], bt[k]);
-        y[k] = ln_gelu2(y[k]);
+        if (!(f.dbg & 2)) y[k] = ln_gelu2(y[k]);
       }
-      if (orow[ip] >= 0) {
+      if (orow[ip] >= 0 && !(f.dbg & 4)) {
         const lnbf16x8 pk = {(__bf16)y[0].x, (__bf16)y[0].y, (__bf16)y[1].x, (__bf16)y[1].y,
                              (__bf16)y[2].x, (__bf16)y[2].y, (__bf16)y[3].x, (__bf16)y[3].y};
         *(lnbf16x8*)(f.out + orow[ip] * g.N + nb + 32 * jp) = pk;
