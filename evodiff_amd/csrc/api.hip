@@ -125,8 +125,8 @@ struct ed_model {
   bool fuse_ln = true;
   DevBuf Abuf1, ln_stats, ln_counters;
   long ln_counter_pitch = 0;
-  unsigned* ln_err_host = nullptr;
-  unsigned* ln_err_dev = nullptr;
+  unsigned* ln_err_host = nullptr;  // ED_AERR_WORDS host-visible words the kernels raise (kernels.hpp), checked by the
+  unsigned* ln_err_dev = nullptr;   //   next call on the model: no per-call validation copies or synchronisations
   DevBuf partials;             // split-K workspace of the small-problem path (run_gemm)
   int split_target = 1024;     // ED_OPT_SPLIT_TARGET: workgroups a small GEMM is cut up to (0 = never split)
   int tuned_split_min_rows = 0;  // ED_OPT_TUNED_SPLIT_MIN_ROWS: problems of at least this many rows that are too small for the
@@ -338,7 +338,7 @@ int run_gemm(ed_model* m, const GemmProblem& p, int kind, hipStream_t s, GemmPro
 // Flat GEMM row R goes to row R of `out`, or with seq_len > 0 to row (R / seq_len) * pitch + row0 + R % seq_len.
 bool fuse_ln_into(ed_model* m, GemmProblem& p, int kind, const float* gamma, const float* beta, void* out, int seq_len,
                   long pitch, long row0) {
-  if (!m->fuse_ln || m->cfg.activation != 1 || !p.a_bf16 || !m->ln_stats.p || !m->ln_err_dev) return false;
+  if (!m->fuse_ln || m->cfg.activation != 1 || !p.a_bf16 || !m->ln_stats.p) return false;
   if (!use_tuned_gemm(m, p) || !gemm_bf16_ln_supported(p)) return false;
   const long row_tiles = (long)p.B * ((p.L + 127) / 128);
   if (row_tiles > m->ln_counter_pitch) return false;
@@ -350,17 +350,25 @@ bool fuse_ln_into(ed_model* m, GemmProblem& p, int kind, const float* gamma, con
   p.ln.out_row0 = row0;
   p.ln.stats = m->ln_stats.p;
   p.ln.counters = m->ln_counters.as<unsigned>() + (long)kind * m->ln_counter_pitch;
-  p.ln.error = m->ln_err_dev;
+  p.ln.error = m->ln_err_dev + ED_AERR_LN_WAIT;
   return true;
 }
 
-// Errors the kernels could only report asynchronously (a bounded inter-workgroup wait that ran out).
+// Errors the kernels could only report asynchronously: raised in host-visible words by an EARLIER launch (out-of-range
+// tokens / timesteps / positions / targets, which the kernels clamp, or a bounded inter-workgroup wait that ran out).
 int check_async_errors(ed_model* m) {
-  if (m->ln_err_host && *(volatile unsigned*)m->ln_err_host) {
-    *(volatile unsigned*)m->ln_err_host = 0;
-    return fail(ED_EHIP, "a fused-LayerNorm kernel gave up waiting for the other workgroups of its row tile in an earlier "
-                         "launch (results of that call are invalid); ed_model_set_option(ED_OPT_FUSE_LN, 0) avoids the exchange");
-  }
+  if (!m->ln_err_host) return ED_OK;
+  volatile unsigned* w = m->ln_err_host;
+  static const char* const what[] = {
+      "a fused-LayerNorm kernel gave up waiting for the other workgroups of its row tile (ED_OPT_FUSE_LN = 0 avoids the exchange)",
+      "token ids outside [0, n_tokens) (D3PM: [0, K)) were clamped", "timesteps outside [0, timesteps) were clamped",
+      "order positions outside [0, L) were clamped", "targets outside [0, n_classes) were clamped"};
+  for (int code = 0; code < 5; ++code)
+    if (w[code]) {
+      for (int k = 0; k < ED_AERR_WORDS; ++k) w[k] = 0;
+      return fail(code == ED_AERR_LN_WAIT ? ED_EHIP : ED_EINVAL,
+                  "an earlier call on this model ran with invalid data: %s; its results are not valid", what[code]);
+    }
   return ED_OK;
 }
 
@@ -460,11 +468,6 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
       HIP_TRY(hipMemsetAsync(m->ln_counters.p, 0, m->ln_counters.bytes, s));  // zero once; launches keep them consistent
     }
     m->ln_counter_pitch = (long)(m->ln_counters.bytes / 12);
-    if (!m->ln_err_host) {
-      HIP_TRY(hipHostMalloc((void**)&m->ln_err_host, 64, hipHostMallocMapped));
-      *m->ln_err_host = 0;
-      HIP_TRY(hipHostGetDevicePointer((void**)&m->ln_err_dev, m->ln_err_host, 0));
-    }
   }
   // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
   m->n_inc = 0;
@@ -872,6 +875,15 @@ int ed_model_create(const ed_config* cfg, int device, ed_model** out) {
   if (!m) return fail(ED_ENOMEM, "out of host memory");
   m->cfg = c;
   m->device = device;
+  hipError_t e = hipHostMalloc((void**)&m->ln_err_host, ED_AERR_WORDS * sizeof(unsigned), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    std::memset(m->ln_err_host, 0, ED_AERR_WORDS * sizeof(unsigned));
+    e = hipHostGetDevicePointer((void**)&m->ln_err_dev, m->ln_err_host, 0);
+  }
+  if (e != hipSuccess) {
+    delete m;
+    return fail(ED_EHIP, "host-visible error words: %s", hipGetErrorString(e));
+  }
   *out = m;
   return ED_OK;
 }
@@ -1017,8 +1029,12 @@ int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* ti
   HIP_TRY(hipSetDevice(m->device));
   if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
+  // range checks on the device (clamp + asynchronous report): the kernels read the model's own, clamped copies
+  LAUNCH_TRY(launch_prepare_ids(tokens_dev, m->tok.as<int64_t>(), (long)B * L, m->cfg.n_tokens, m->ln_err_dev, ED_AERR_TOKEN, s));
+  if (m->cfg.timesteps > 0)
+    LAUNCH_TRY(launch_prepare_ids(timesteps_dev, m->tvec.as<int64_t>(), B, m->cfg.timesteps, m->ln_err_dev, ED_AERR_TIMESTEP, s));
   m->probing_now = m->probe_every > 0;
-  rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, STEP_PLAIN, s);
+  rc = run_embed(m, m->tok.as<int64_t>(), m->cfg.timesteps > 0 ? m->tvec.as<int64_t>() : nullptr, B, L, STEP_PLAIN, s);
   if (!rc && acts_dev)
     HIP_TRY(hipMemcpyAsync(acts_dev, m->X.p, (size_t)B * L * m->cfg.d_model * 4, hipMemcpyDeviceToDevice, s));
   if (!rc) rc = run_blocks(m, B, L, precision, acts_dev, false, STEP_PLAIN, nullptr, s);
@@ -1047,21 +1063,15 @@ int ed_score_nll(ed_model* m, const int64_t* tokens_dev, const int64_t* timestep
   if (n_classes < 1 || n_classes > m->cfg.n_tokens) return fail(ED_EINVAL, "n_classes must be in [1, n_tokens]");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(m->device));
-  {  // the target indexes the logits: validate it on the host before any kernel uses it
-    const size_t n = (size_t)B * L;
-    std::vector<int64_t> tg(n);
-    std::vector<uint8_t> sel(select_dev ? n : 0);
-    HIP_TRY(hipMemcpyAsync(tg.data(), targets_dev, n * 8, hipMemcpyDeviceToHost, s));
-    if (select_dev) HIP_TRY(hipMemcpyAsync(sel.data(), select_dev, n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    for (size_t i = 0; i < n; ++i)
-      if ((!select_dev || sel[i]) && (tg[i] < 0 || tg[i] >= n_classes))
-        return fail(ED_EINVAL, "targets[%zu] = %lld is outside [0, n_classes=%d)", i, (long long)tg[i], n_classes);
-  }
   if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
+  // range checks on the device (clamp + asynchronous report; the scoring tail clamps the targets itself)
+  LAUNCH_TRY(launch_prepare_ids(tokens_dev, m->tok.as<int64_t>(), (long)B * L, m->cfg.n_tokens, m->ln_err_dev, ED_AERR_TOKEN, s));
+  if (m->cfg.timesteps > 0)
+    LAUNCH_TRY(launch_prepare_ids(timesteps_dev, m->tvec.as<int64_t>(), B, m->cfg.timesteps, m->ln_err_dev, ED_AERR_TIMESTEP, s));
+  LAUNCH_TRY(launch_check_targets(targets_dev, select_dev, (long)B * L, n_classes, m->ln_err_dev, s));
   m->probing_now = m->probe_every > 0;
-  rc = run_embed(m, tokens_dev, m->cfg.timesteps > 0 ? timesteps_dev : nullptr, B, L, STEP_PLAIN, s);
+  rc = run_embed(m, m->tok.as<int64_t>(), m->cfg.timesteps > 0 ? m->tvec.as<int64_t>() : nullptr, B, L, STEP_PLAIN, s);
   if (!rc) rc = run_blocks(m, B, L, precision, nullptr, false, STEP_PLAIN, nullptr, s);
   if (!rc) {
     Probe pr(m, s);
@@ -1086,22 +1096,18 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
   if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
-  // positions are validated on the host before any kernel indexes with them
-  std::vector<int32_t> ord((size_t)n_steps);
-  HIP_TRY(hipMemcpyAsync(ord.data(), order_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  for (int i = 0; i < n_steps; ++i)
-    if (ord[i] < 0 || ord[i] >= L) return fail(ED_EINVAL, "order[%d] = %d is outside [0, %d)", i, ord[i], L);
   {
     const size_t ob = m->order.bytes, ub = m->uni.bytes;
     HIP_TRY(m->order.ensure((size_t)n_steps * 4));
     HIP_TRY(m->uni.ensure((size_t)n_steps * B * 4));
     if (m->order.bytes != ob || m->uni.bytes != ub) m->drop_graphs();
   }
-  HIP_TRY(hipMemcpyAsync(m->order.p, order_dev, (size_t)n_steps * 4, hipMemcpyDeviceToDevice, s));
+  // positions and tokens are range-checked on the device while they are copied into the model's buffers (clamp +
+  // asynchronous report): no copy to the host, no synchronisation
+  LAUNCH_TRY(launch_prepare_order(order_dev, m->order.as<int>(), n_steps, L, m->ln_err_dev, s));
   HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)n_steps * B * 4, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
+  LAUNCH_TRY(launch_prepare_ids(tokens_dev, m->tok.as<int64_t>(), (long)B * L, m->cfg.n_tokens, m->ln_err_dev, ED_AERR_TOKEN, s));
+  LAUNCH_TRY(launch_init_state(m->state.as<StepState>(), 0, 0, s));
   if ((rc = run_loop(m, MODE_OADM, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s))) return rc;
   HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
   return ED_OK;
@@ -1144,13 +1150,10 @@ int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, in
     HIP_TRY(m->uni.ensure((size_t)n_steps * B * 4));
     if (m->order.bytes != ob || m->uni.bytes != ub) m->drop_graphs();
   }
-  std::vector<int32_t> ord((size_t)n_steps);
-  for (int i = 0; i < n_steps; ++i) ord[i] = i;  // step i extends the sequence from position i
-  HIP_TRY(hipMemcpyAsync(m->order.p, ord.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));  // (ord is a stack-lifetime host buffer)
+  LAUNCH_TRY(launch_prepare_order(nullptr, m->order.as<int>(), n_steps, L, m->ln_err_dev, s));  // step i extends position i
   HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)n_steps * B * 4, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
+  LAUNCH_TRY(launch_prepare_ids(tokens_dev, m->tok.as<int64_t>(), (long)B * L, c.n_tokens, m->ln_err_dev, ED_AERR_TOKEN, s));
+  LAUNCH_TRY(launch_init_state(m->state.as<StepState>(), 0, 0, s));
   if ((rc = run_loop(m, MODE_AR, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s))) return rc;
   HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
   return ED_OK;
@@ -1172,14 +1175,6 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
   if ((rc = check_async_errors(m))) return rc;
   if ((rc = ensure_workspace(m, B, L, precision, s))) return rc;
   if (n_steps == 0) return ED_OK;
-  // x_t indexes Q's columns: validate the token range on the host first
-  {
-    std::vector<int64_t> tk((size_t)B * L);
-    HIP_TRY(hipMemcpyAsync(tk.data(), tokens_dev, tk.size() * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    for (size_t i = 0; i < tk.size(); ++i)
-      if (tk[i] < 0 || tk[i] >= K) return fail(ED_EINVAL, "tokens[%zu] = %lld is outside [0, K=%d)", i, (long long)tk[i], K);
-  }
   const size_t kk = (size_t)T * K * K;
   {
     const size_t qb = m->qbuf.bytes, ub = m->uni.bytes;
@@ -1190,11 +1185,9 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
   HIP_TRY(hipMemcpyAsync(m->qbuf.p, Q_dev, kk * 8, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(m->qbuf.as<double>() + kk, Qbar_dev, kk * 8, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)T * B * L * 4, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(m->tok.p, tokens_dev, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
-  StepState st{0, t_start};
-  HIP_TRY(hipMemsetAsync(m->state.p, 0, 256, s));
-  HIP_TRY(hipMemcpyAsync(m->state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));  // `st` lives on this stack frame
+  // x_t indexes Q's columns: range-checked on the device while it is copied (clamp + asynchronous report)
+  LAUNCH_TRY(launch_prepare_ids(tokens_dev, m->tok.as<int64_t>(), (long)B * L, K, m->ln_err_dev, ED_AERR_TOKEN, s));
+  LAUNCH_TRY(launch_init_state(m->state.as<StepState>(), 0, t_start, s));
   if ((rc = run_loop(m, MODE_D3PM, B, L, K, n_steps, precision, use_graph, nullptr, post_dev, s))) return rc;
   HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
   return ED_OK;
@@ -1408,6 +1401,15 @@ int ed_model_set_option(ed_model* m, int option, int value) {
   HIP_TRY(hipSetDevice(m->device));
   m->drop_graphs();  // the captured launch sequences depend on both options
   return ED_OK;
+}
+
+int ed_model_check_errors(ed_model* m, void* stream, int synchronize) {
+  if (!m) return fail(ED_EINVAL, "null model handle");
+  if (synchronize) {
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  }
+  return check_async_errors(m);
 }
 
 int ed_probe_config(ed_model* m, int every_n_steps) {

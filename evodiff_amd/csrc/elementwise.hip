@@ -670,6 +670,44 @@ __global__ __launch_bounds__(256) void final_d3pm_kernel(const float* __restrict
 }
 
 __global__ void advance_step_kernel(StepState* s) { s->step += 1; }
+__global__ void init_state_kernel(StepState* s, int step, int t_start) {
+  s->step = step;
+  s->t_start = t_start;
+}
+
+// Validation on the device (no copy to the host, no synchronisation): out-of-range values are clamped, so that no
+// kernel ever indexes outside a table or a sequence, and reported through a host-visible word the next call checks.
+__global__ __launch_bounds__(256) void prepare_order_kernel(const int* __restrict__ src, int* __restrict__ dst, int n,
+                                                            int hi, unsigned* err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int v = src ? src[i] : i;
+  if (v < 0 || v >= hi) {
+    err[ED_AERR_ORDER] = 1u;
+    v = v < 0 ? 0 : hi - 1;
+  }
+  dst[i] = v;
+}
+__global__ __launch_bounds__(256) void prepare_ids_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst,
+                                                          long n, int hi, unsigned* err, int code) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long v = src[i];
+  if (v < 0 || v >= hi) {
+    err[code] = 1u;
+    v = hi - 1;
+  }
+  dst[i] = v;
+}
+__global__ __launch_bounds__(256) void check_targets_kernel(const int64_t* __restrict__ targets,
+                                                            const uint8_t* __restrict__ select, long n, int n_classes,
+                                                            unsigned* err) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (select != nullptr && select[i] == 0) return;
+  const long v = targets[i];
+  if (v < 0 || v >= n_classes) err[ED_AERR_TARGET] = 1u;
+}
 
 }  // namespace
 
@@ -844,6 +882,32 @@ hipError_t launch_final_d3pm(const float* X, const float* gamma, const float* be
                      Qbar, uniforms, state, post, B, L, D, K, n_timesteps)
   ED_NCH_DISPATCH(D, ED_CALL);
 #undef ED_CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_order(const int* src, int* dst, int n, int hi, unsigned* err, hipStream_t stream) {
+  if (n <= 0 || hi <= 0 || !dst || !err) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(prepare_order_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n, hi, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_ids(const int64_t* src, int64_t* dst, long n, int hi, unsigned* err, int code,
+                              hipStream_t stream) {
+  if (n <= 0 || hi <= 0 || !src || !dst || !err) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(prepare_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n, hi, err, code);
+  return hipGetLastError();
+}
+
+hipError_t launch_check_targets(const int64_t* targets, const uint8_t* select, long n, int n_classes, unsigned* err,
+                                hipStream_t stream) {
+  if (n <= 0 || !targets || !err) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(check_targets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, targets, select, n,
+                     n_classes, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_init_state(StepState* state, int step, int t_start, hipStream_t stream) {
+  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, state, step, t_start);
   return hipGetLastError();
 }
 

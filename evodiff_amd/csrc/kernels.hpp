@@ -188,4 +188,18 @@ hipError_t launch_final_d3pm(const float* X, const float* gamma, const float* be
 
 hipError_t launch_advance_step(StepState* state, hipStream_t stream);
 
+// Asynchronous error words (host-visible memory, one 4-byte word per code): kernels raise them instead of the host
+// validating device data with a copy and a synchronisation per call; the C ABI reports them on the next call.
+enum { ED_AERR_LN_WAIT = 0, ED_AERR_TOKEN = 1, ED_AERR_TIMESTEP = 2, ED_AERR_ORDER = 3, ED_AERR_TARGET = 4, ED_AERR_WORDS = 16 };
+
+// dst[i] = src[i] clamped into [0, hi) (src == nullptr: dst[i] = i), raising err[code] when a value was outside.
+hipError_t launch_prepare_order(const int* src, int* dst, int n, int hi, unsigned* err, hipStream_t stream);
+// dst[i] = src[i], values outside [0, hi) replaced by hi - 1 and reported in err[code] (tokens, timesteps)
+hipError_t launch_prepare_ids(const int64_t* src, int64_t* dst, long n, int hi, unsigned* err, int code, hipStream_t stream);
+// raises err[ED_AERR_TARGET] when a selected target is outside [0, n_classes) (the scoring tail itself clamps)
+hipError_t launch_check_targets(const int64_t* targets, const uint8_t* select, long n, int n_classes, unsigned* err,
+                                hipStream_t stream);
+// *state = {step, t_start}
+hipError_t launch_init_state(StepState* state, int step, int t_start, hipStream_t stream);
+
 }  // namespace ed

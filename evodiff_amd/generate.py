@@ -58,7 +58,7 @@ def generate_oaardm(model, tokenizer, seq_len, penalty=None, batch_size=3, devic
             # Rare path: the forward runs on the GPU, the per-sequence re-draw logic stays on the host side.
             timestep = torch.zeros(batch_size, dtype=torch.long, device=device)
             for s, i in enumerate(int(v) for v in loc):
-                p = torch.softmax(model(sample, timestep)[:, i, :n_draw], dim=1)
+                p = torch.softmax(model(sample, timestep, validate=False)[:, i, :n_draw], dim=1)
                 p_sample = _inverse_cdf(p, uniforms[s])
                 left = sample[:, i - 1] if i > 0 else torch.full_like(p_sample, -1)
                 right = sample[:, i + 1] if i < seq_len - 1 else torch.full_like(p_sample, -1)
@@ -87,7 +87,7 @@ def generate_oaardm_order_opt(model, tokenizer, seq_len, penalty=None, batch_siz
     uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device)
     with torch.no_grad():
         for s in range(seq_len):
-            p = torch.softmax(model(sample, timestep)[:, :, :n_draw], dim=-1)
+            p = torch.softmax(model(sample, timestep, validate=False)[:, :, :n_draw], dim=-1)
             p[(sample != mask).unsqueeze(-1).expand(p.shape)] = 0        # ignore positions already sampled
             # argmax over the FLATTENED batch, as there; the rows are copies of each other, and only the FIRST maximum
             # (CPU torch.argmax's choice) indexes row 0 - a device argmax does not promise which tie it returns

@@ -192,8 +192,36 @@ class ByteNetLMTime(nn.Module):
             raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
 
     # ------------------------------------------------------------------ reference call surface
-    def forward(self, x, y, input_mask=None, return_blocks=False):
-        """``model(x, y)``: x (B, L) int64 tokens, y (B,) int64 timesteps -> (B, L, n_tokens) fp32 logits."""
+    def _check_ranges(self, x, y, targets=None, select=None, n_classes=None):
+        """One fused range check of a call's index tensors: a single small device-to-host copy (= one synchronisation)
+        instead of one per tensor and bound.  The C ABI itself never synchronises: it clamps on the device and reports
+        on the next call (``check_errors``); this up-front check keeps the reference's behaviour of raising at the call."""
+        flags = [((x < 0) | (x >= self.hparams["n_tokens"])).any()]
+        T = self.hparams["timesteps"]
+        flags.append(((y < 0) | (y >= T)).any() if T > 0 else torch.zeros((), dtype=torch.bool, device=x.device))
+        if targets is not None:
+            bad = (targets < 0) | (targets >= n_classes)
+            flags.append((bad & select.bool()).any() if select is not None else bad.any())
+        bad_x, bad_y, *bad_t = torch.stack(flags).cpu().tolist()
+        if bad_x:
+            raise IndexError("token id out of range")
+        if bad_y:
+            raise IndexError("timestep out of range")
+        if bad_t and bad_t[0]:
+            raise _lib.EvoDiffHipError("targets of selected positions must be in [0, n_classes=%d)" % n_classes)
+
+    def check_errors(self, synchronize=True):
+        """Raise what kernels of earlier calls reported asynchronously (out-of-range data they clamped, a fused
+        LayerNorm exchange that timed out); see ``ed_model_check_errors``."""
+        if self._handle is None:
+            return
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().ed_model_check_errors(self._handle, stream, int(bool(synchronize))))
+
+    def forward(self, x, y, input_mask=None, return_blocks=False, validate=True):
+        """``model(x, y)``: x (B, L) int64 tokens, y (B,) int64 timesteps -> (B, L, n_tokens) fp32 logits.
+        ``validate=False`` (not in the reference) skips the up-front range check and its synchronisation - for loops
+        that feed the model its own samples; the kernels then clamp and ``check_errors`` reports."""
         if input_mask is not None:
             raise NotImplementedError("input_mask is only used by training (train.py:397); not on the sampling path")
         if x.dim() != 2:
@@ -204,14 +232,11 @@ class ByteNetLMTime(nn.Module):
         lib = _lib.load()
         B, L = x.shape
         x = x.to(torch.long).contiguous()
-        if int(x.min()) < 0 or int(x.max()) >= self.hparams["n_tokens"]:
-            raise IndexError("token id out of range")
         y = y.to(device=x.device, dtype=torch.long).contiguous()
-        if self.hparams["timesteps"] > 0:
-            if y.numel() != B:
-                raise ValueError("y must have one timestep per sequence")
-            if int(y.min()) < 0 or int(y.max()) >= self.hparams["timesteps"]:
-                raise IndexError("timestep out of range")
+        if self.hparams["timesteps"] > 0 and y.numel() != B:
+            raise ValueError("y must have one timestep per sequence")
+        if validate:
+            self._check_ranges(x, y)
         logits = torch.empty((B, L, self.hparams["n_tokens"]), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
@@ -224,7 +249,7 @@ class ByteNetLMTime(nn.Module):
             _lib.check(lib.ed_forward(handle, x.data_ptr(), y.data_ptr(), B, L, logits.data_ptr(), self._prec(), stream))
         return logits
 
-    def score_nll(self, x, y, targets, select=None, n_classes=None):
+    def score_nll(self, x, y, targets, select=None, n_classes=None, validate=True):
         """Forward + per-position cross entropy against ``targets`` (analysis/sequence_perp.py:125-154) on the GPU:
         (B, L) fp32, zero where ``select`` (B, L) is false.  The logits are never materialised."""
         if not x.is_cuda:
@@ -234,10 +259,8 @@ class ByteNetLMTime(nn.Module):
         B, L = x.shape
         n_classes = self.hparams["n_tokens"] if n_classes is None else int(n_classes)
         x = x.to(torch.long).contiguous()
-        if int(x.min()) < 0 or int(x.max()) >= self.hparams["n_tokens"]:
-            raise IndexError("token id out of range")
         y = y.to(device=x.device, dtype=torch.long).contiguous()
-        if self.hparams["timesteps"] > 0 and (y.numel() != B or int(y.min()) < 0 or int(y.max()) >= self.hparams["timesteps"]):
+        if self.hparams["timesteps"] > 0 and y.numel() != B:
             raise IndexError("y must hold one timestep in [0, timesteps) per sequence")
         targets = targets.to(device=x.device, dtype=torch.long).contiguous()
         if targets.shape != x.shape:
@@ -245,6 +268,8 @@ class ByteNetLMTime(nn.Module):
         sel = None
         if select is not None:
             sel = select.to(device=x.device).reshape(B, L).ne(0).to(torch.uint8).contiguous()
+        if validate:
+            self._check_ranges(x, y, targets, sel, n_classes)
         nll = torch.empty((B, L), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
@@ -261,6 +286,10 @@ class ByteNetLMTime(nn.Module):
         B, L = sample.shape
         n_steps = int(order.numel())
         assert sample.dtype == torch.long and sample.is_contiguous()
+        if not order.is_cuda and n_steps and (int(order.min()) < 0 or int(order.max()) >= L):
+            # an order built on the host (np.random.shuffle in generate_oaardm) is checked there, for free; one that
+            # already lives on the GPU is range-checked by the library on the device (clamped, reported by the next call)
+            raise _lib.EvoDiffHipError("order positions must be in [0, L=%d)" % L)
         order = order.to(device=sample.device, dtype=torch.int32).contiguous()
         uniforms = uniforms.to(device=sample.device, dtype=torch.float32).contiguous()
         if uniforms.shape != (n_steps, B):

@@ -17,6 +17,11 @@
  *   - One model handle serves one device; a handle is not thread-safe (the reference is
  *     single-threaded on this path as well).
  *   - No CPU fallback exists anywhere in this library.
+ *   - Device data is validated on the device, never by a copy to the host: token ids, timesteps, OA-DM positions and
+ *     scoring targets outside their range are CLAMPED by the kernels (nothing ever indexes outside a table or a
+ *     sequence) and reported asynchronously - the NEXT call on the model (or ed_model_check_errors) returns ED_EINVAL
+ *     with a message naming what was out of range; the results of the offending call are not valid.  No compute entry
+ *     point synchronises the stream.
  */
 #ifndef EVODIFF_HIP_H
 #define EVODIFF_HIP_H
@@ -93,10 +98,9 @@ int64_t ed_model_num_params(const ed_model* m);
 /* Replaces: ByteNetLMTime.forward(x, y, input_mask=None) (evodiff/model.py:170-173).
  * tokens_dev int64 (B, L); timesteps_dev int64 (B,) (ignored when cfg.timesteps == 0);
  * logits_dev fp32 (B, L, n_tokens).
- * Token ids and timesteps are NOT validated by the C ABI (that would need a device-to-host copy per call): an id
- * outside [0, n_tokens) is embedded as id n_tokens-1 and a timestep outside [0, timesteps) is clamped into it, so a
- * kernel never indexes outside a table.  The Python layer (evodiff_amd.model) checks the ranges and raises
- * IndexError like nn.Embedding would. */
+ * Token ids and timesteps are range-checked on the device: an id outside [0, n_tokens) is embedded as id n_tokens-1, a
+ * timestep outside [0, timesteps) as timesteps-1, and the next call reports it (see Conventions).  The Python layer
+ * (evodiff_amd.model) checks the ranges up front (one fused check) and raises IndexError like nn.Embedding would. */
 int ed_forward(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
                float* logits_dev, int precision, void* stream);
 /* Debug/validation variant: additionally copies the residual stream after the embedding and after
@@ -109,7 +113,8 @@ int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* ti
  * by OAMaskedCrossEntropyLoss, evodiff/losses.py:57-61, and by the D3PM branch, sequence_perp.py:133-134); the
  * logits never leave the GPU.  select_dev (B*L bytes, may be NULL = every position): positions with a zero byte
  * are skipped and score 0 (the OA-DM mask).  nll_dev receives B*L fp32 values; the caller sums them.
- * Targets of selected positions must be in [0, n_classes): ED_EINVAL otherwise. */
+ * Targets of selected positions must be in [0, n_classes): others score against class 0 and are reported by the next
+ * call (see Conventions). */
 int ed_score_nll(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, const int64_t* targets_dev,
                  const uint8_t* select_dev, int B, int L, int n_classes, float* nll_dev, int precision, void* stream);
 
@@ -147,6 +152,12 @@ int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, in
 int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const double* Qbar_dev,
                    const float* uniforms_dev, int B, int L, int K, int t_start, int n_steps,
                    double* post_dev, int precision, int use_graph, void* stream);
+
+/* Reports (and clears) what kernels of earlier calls on the model raised asynchronously: out-of-range tokens,
+ * timesteps, positions or targets (ED_EINVAL), or a fused-LayerNorm exchange that timed out (ED_EHIP); ED_OK if
+ * nothing is pending.  synchronize != 0 waits for `stream` first, so that everything launched so far is covered.
+ * No counterpart in the reference (its errors are Python exceptions raised by the indexing op itself). */
+int ed_model_check_errors(ed_model* m, void* stream, int synchronize);
 
 /* Execution options (no counterpart in the reference).  They select kernels and what is recomputed, never the
  * function: with ED_PREC_FP32 the results are bit-identical under every setting; with ED_PREC_BF16 different settings

@@ -600,6 +600,41 @@ def test_errors_are_raised_not_faults(dev):
         m.d3pm_sample(sample, torch.zeros(1), torch.zeros(1), torch.zeros(1), 26)               # no timesteps
 
 
+def test_device_side_validation_reports_on_the_next_call(dev):
+    """The C ABI validates device data on the device: no copy to the host and no synchronisation
+    per call.  Out-of-range positions / tokens / targets are clamped (no fault, nothing indexed outside a table) and
+    the NEXT call - or ed_model_check_errors - reports them and clears the report."""
+    from evodiff_amd import _lib
+    oracle = R.build_model(TINY, None, 1)
+    m = product_model(oracle, TINY)
+    B, L = 2, 8
+    uni = torch.full((1, B), 0.5, device=dev)
+    sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+    m.oadm_sample(sample, torch.tensor([L], device=dev), uni, R.OADM_DRAW)         # order on the GPU: not checked by Python
+    with pytest.raises(_lib.EvoDiffHipError, match="order positions"):
+        m.check_errors()
+    assert int((sample[:, :L - 1] != R.MASK_ID).sum()) == 0 and int((sample[:, L - 1] < R.OADM_DRAW).sum()) == B  # clamped to L-1
+    m.check_errors()                                                                # reported once, then clear
+    good = torch.zeros((B, L), dtype=torch.long, device=dev)
+    bad = good.clone()
+    bad[1, 3] = 31
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    want = m(torch.where(bad == 31, torch.full_like(bad, 30), bad), t)
+    got = m(bad, t, validate=False)                                                 # embedded as id n_tokens - 1
+    assert torch.equal(got, want)
+    with pytest.raises(_lib.EvoDiffHipError, match="token ids"):
+        m(good, t)                                                                  # the next call reports it ...
+    assert torch.isfinite(m(good, t)).all()                                         # ... once
+    m.score_nll(good, t, torch.full_like(good, 25), n_classes=21, validate=False)
+    with pytest.raises(_lib.EvoDiffHipError, match="targets"):
+        m.check_errors()
+    # the sampler loops feed the model its own samples without the up-front check: no error pending afterwards
+    from evodiff_amd.generate import generate_oaardm_order_opt
+    from evodiff_amd.utils import Tokenizer
+    generate_oaardm_order_opt(m, Tokenizer(), 12, batch_size=2, device=dev)
+    m.check_errors()
+
+
 def test_order_opt_sampler_against_reference_trace(golden_dir, dev):
     """generate_oaardm_order_opt (generate.py:151-177), fp32, against the trace the reference's own
     source produced: the same positions are picked and the same tokens drawn wherever neither the argmax nor the
