@@ -85,16 +85,19 @@ def generate_oaardm_order_opt(model, tokenizer, seq_len, penalty=None, batch_siz
     if uniforms is None:
         uniforms = torch.rand(seq_len, dtype=torch.float32, device=device)
     uniforms = torch.as_tensor(uniforms, dtype=torch.float32).to(device)
+    index = torch.arange(batch_size * seq_len * n_draw, device=device)
     with torch.no_grad():
         for s in range(seq_len):
             p = torch.softmax(model(sample, timestep, validate=False)[:, :, :n_draw], dim=-1)
             p[(sample != mask).unsqueeze(-1).expand(p.shape)] = 0        # ignore positions already sampled
             # argmax over the FLATTENED batch, as there; the rows are copies of each other, and only the FIRST maximum
             # (CPU torch.argmax's choice) indexes row 0 - a device argmax does not promise which tie it returns
+            # (the first maximum as a min over the indices that attain it: torch.nonzero would synchronise every step)
             flat = p.view(-1)
-            idx = torch.nonzero(flat == flat.max())[0]
+            idx = torch.where(flat == flat.max(), index, index[-1]).min()
             pos = torch.div(idx, p.shape[-1], rounding_mode='trunc')
-            sample[:, pos] = _inverse_cdf(p[0, pos], uniforms[s].reshape(1))
+            tok = _inverse_cdf(p[0].index_select(0, pos.reshape(1)), uniforms[s].reshape(1))
+            sample.index_copy_(1, pos.reshape(1), tok.reshape(1, 1).expand(batch_size, 1))
     return sample, _strings(tokenizer, sample)
 
 
