@@ -751,9 +751,9 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   LAUNCH_TRY(pr.begin());
   LAUNCH_TRY(launch_final_oadm(x, 1, 30, m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),
                                m->order.as<int>(), m->uni.as<float>(), m->state.as<StepState>(), probs, B, L, D, n, s,
-                               /*write_shift=*/1));
+                               /*write_shift=*/1, /*advance=*/B <= ED_ADVANCE_IN_TAIL_MAX_B));
   LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * n * D, (double)B * D * 4.0));
-  LAUNCH_TRY(launch_advance_step(m->state.as<StepState>(), s));
+  if (B > ED_ADVANCE_IN_TAIL_MAX_B) LAUNCH_TRY(launch_advance_step(m->state.as<StepState>(), s));
   return ED_OK;
 }
 
@@ -774,8 +774,10 @@ int run_step(ed_model* m, int mode, int variant, int B, int L, int n, int prec, 
     const int sf = pruned ? m->plan_s_final : 1;
     LAUNCH_TRY(launch_final_oadm(xf, L / sf, __builtin_ctz(sf), m->last_g, m->last_b, m->dec_w, m->dec_b,
                                  m->tok.as<int64_t>(), m->order.as<int>(), m->uni.as<float>(),
-                                 m->state.as<StepState>(), probs, B, L, c.d_model, n, s));
+                                 m->state.as<StepState>(), probs, B, L, c.d_model, n, s, 0,
+                                 /*advance=*/B <= ED_ADVANCE_IN_TAIL_MAX_B));
     LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * n * c.d_model, (double)B * c.d_model * 4.0));
+    if (B <= ED_ADVANCE_IN_TAIL_MAX_B) return ED_OK;
   } else {
     const size_t kk = (size_t)c.timesteps * n * n;
     LAUNCH_TRY(launch_final_d3pm(m->X.as<float>(), m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),

@@ -586,9 +586,9 @@ template <int NCH>
 __global__ __launch_bounds__(64 * OADM_WAVES) void final_oadm_kernel(const float* __restrict__ X, const float* gamma,
                                                         const float* beta, const float* dec_w, const float* dec_b,
                                                         int64_t* tokens, const int* __restrict__ order,
-                                                        const float* __restrict__ uniforms, const StepState* state,
+                                                        const float* __restrict__ uniforms, StepState* state,
                                                         float* probs, int B, int L, int D, int n_draw,
-                                                        int x_rows_per_seq, int x_shift, int write_shift) {
+                                                        int x_rows_per_seq, int x_shift, int write_shift, int advance) {
   __shared__ float logits[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
   const int step = state->step;
@@ -613,6 +613,15 @@ __global__ __launch_bounds__(64 * OADM_WAVES) void final_oadm_kernel(const float
   if (idx > n_draw - 1) idx = n_draw - 1;
   // write_shift = 1 (autoregressive steps, generate.py:241-244): the draw from position pos is the NEXT token
   if (lane == 0 && pos + write_shift < L) tokens[row + write_shift] = idx;
+  // the step counter moves on once the LAST workgroup is done: each one read it when it started, so none reads the
+  // new value (saves the one-thread advance launch at the end of every step)
+  if (advance && lane == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(&state->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == gridDim.x - 1) {
+      __hip_atomic_store(&state->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state->step, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -673,6 +682,7 @@ __global__ void advance_step_kernel(StepState* s) { s->step += 1; }
 __global__ void init_state_kernel(StepState* s, int step, int t_start) {
   s->step = step;
   s->t_start = t_start;
+  s->done = 0;
 }
 
 // Validation on the device (no copy to the host, no synchronisation): out-of-range values are clamped, so that no
@@ -857,13 +867,13 @@ hipError_t launch_final_nll(const float* X, const float* gamma, const float* bet
 
 hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
                              const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
-                             const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
-                             int n_draw, hipStream_t stream, int write_shift) {
+                             const float* uniforms, StepState* state, float* probs, int B, int L, int D,
+                             int n_draw, hipStream_t stream, int write_shift, bool advance) {
   if (D % 4 != 0 || n_draw > 64 || n_draw < 1 || B <= 0) return hipErrorInvalidValue;
   const dim3 grid(B), block(64 * OADM_WAVES);
 #define ED_CALL(N)                                                                                             \
   hipLaunchKernelGGL((final_oadm_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, tokens, order, \
-                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift, write_shift)
+                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift, write_shift, advance ? 1 : 0)
   ED_NCH_DISPATCH(D, ED_CALL);
 #undef ED_CALL
   return hipGetLastError();

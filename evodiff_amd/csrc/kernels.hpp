@@ -18,8 +18,9 @@ __host__ __device__ inline bf16_t f32_to_bf16_bits(float f) {
 
 // Device-resident per-call scalars read by kernels inside a captured graph.
 struct StepState {
-  int step;     // index of the current sampling step (advanced by advance_step_kernel)
-  int t_start;  // D3PM: t of step 0; the current t is t_start - step
+  int step;       // index of the current sampling step (advanced by advance_step_kernel, or by the step tail itself)
+  int t_start;    // D3PM: t of step 0; the current t is t_start - step
+  unsigned done;  // workgroups of the OA-DM step tail that have finished (the last one advances `step` and clears this)
 };
 
 // Device-side row selector (order == nullptr: always 0); lets row maps that depend on the OA-DM positions live
@@ -176,8 +177,12 @@ hipError_t launch_final_logits(const float* X, const float* gamma, const float* 
 // X holds x_rows_per_seq rows per sequence; the row of position pos is pos >> x_shift.
 hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
                              const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
-                             const float* uniforms, const StepState* state, float* probs, int B, int L, int D,
-                             int n_draw, hipStream_t stream, int write_shift = 0);
+                             const float* uniforms, StepState* state, float* probs, int B, int L, int D,
+                             int n_draw, hipStream_t stream, int write_shift = 0, bool advance = false);
+// Batches up to this size advance the step counter inside the OA-DM step tail (the workgroup that finishes last does
+// it: every workgroup has read the counter by then) instead of a launch of its own; larger ones would queue on the
+// ticket word for longer than that launch takes.
+constexpr int ED_ADVANCE_IN_TAIL_MAX_B = 128;
 
 // D3PM step tail (generate.py:279-298): softmax over K, fp64 posterior with Q[t] / Qbar[t-1], one draw per
 // position, in place on tokens.
