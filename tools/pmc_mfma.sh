@@ -10,11 +10,11 @@ run() {
   tag=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/$tag -- python3 $GRAFT_REPO_ROOT/tools/gemm_bench.py --iters 20 "$@" > $out/$tag.log 2>&1 || { echo "pass $tag failed"; tail -5 $out/$tag.log; exit 1; }
 }
-run conv_d1   --B 64 --L 256 --taps 5 --dil 1   --kernel 0 --out_bf16 1
-run conv_d16  --B 64 --L 256 --taps 5 --dil 16  --kernel 0 --out_bf16 1
-run conv_d64  --B 64 --L 256 --taps 5 --dil 64  --kernel 0 --out_bf16 1
-run pff1      --B 64 --L 256 --flat 1 --taps 1 --kernel 0 --out_bf16 1
-run pff2      --B 64 --L 256 --flat 1 --taps 1 --resid 1 --kernel 0
+run conv_d1   --B 64 --L 256 --taps 5 --dil 1   --kernel ${PMC_KERNEL:-0} --out_bf16 1
+run conv_d16  --B 64 --L 256 --taps 5 --dil 16  --kernel ${PMC_KERNEL:-0} --out_bf16 1
+run conv_d64  --B 64 --L 256 --taps 5 --dil 64  --kernel ${PMC_KERNEL:-0} --out_bf16 1
+run pff1      --B 64 --L 256 --flat 1 --taps 1 --kernel ${PMC_KERNEL:-0} --out_bf16 1
+run pff2      --B 64 --L 256 --flat 1 --taps 1 --resid 1 --kernel ${PMC_KERNEL:-0}
 python3 - "$out" <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma.txt
 import csv, glob, os, sys, collections
 out = sys.argv[1]
