@@ -1,6 +1,6 @@
 """Same-process A/B of an execution option: ms per diffusion step with the option at each of the given values,
 alternating, per configuration (bf16, graph replay).
-    python tools/opt_ab.py fuse_ln 0 1 [--cfg cfg2 cfg3 cfg5 ...]"""
+    python tools/opt_ab.py fuse_ln 0 1 [--pre other_option=value ...] [--cfg cfg2 cfg3 cfg5 ...]   (--cfg last)"""
 import sys
 import time
 
@@ -18,6 +18,11 @@ cfgs = ["cfg2"]
 if "--cfg" in args:
     k = args.index("--cfg")
     cfgs, args = args[k + 1:], args[:k]
+pre = {}
+if "--pre" in args:                       # other options held fixed: --pre name=value name=value
+    k = args.index("--pre")
+    pre = dict((a.split("=")[0], int(a.split("=")[1])) for a in args[k + 1:])
+    args = args[:k]
 option, values = args[0], [int(v) for v in args[1:]]
 dev = torch.device("cuda", 0)
 for name in cfgs:
@@ -34,6 +39,8 @@ for name in cfgs:
         order = torch.from_numpy(np.random.default_rng(0).permutation(L)[:n].astype(np.int32))
         uni = torch.rand((n, B), device=dev)
     m.precision = "bf16"
+    for name_, value_ in pre.items():
+        m.set_option(name_, value_)
     best = {v: 1e9 for v in values}
     for rep in range(3):
         for v in values:
