@@ -16,7 +16,10 @@ from oracle import bytenet_ref as R
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
-BF16_TOL = 3e-2          # relative to max |logit|; bf16 operands (8-bit mantissa) through up to 56 residual blocks
+# relative to max |logit|; bf16 operands (8-bit mantissa) through up to 56 residual blocks.  Measured against the oracle on
+# these tests' shapes (tools/bf16_error_survey.py, profiles/r02_bf16_error_survey.txt): 6.3e-3 ... 1.3e-2 (largest:
+# 640M, L = 512); the stated tolerance is 1.5 x the largest measured value (round 1 stated 3e-2 without the survey).
+BF16_TOL = 2e-2
 DRAW_MARGIN_FP32 = 1e-4  # probability mass; draws closer than this to a CDF boundary may differ
 DRAW_MARGIN_BF16 = 5e-2
 
@@ -657,7 +660,7 @@ def test_order_opt_sampler_against_reference_trace(golden_dir, dev):
     assert strings == [str(s) for s in g["strings"]]
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", BF16_TOL)])
 def test_scoring_against_reference_losses(golden_dir, dev, precision, tol):
     """sum_nll_mask (analysis/sequence_perp.py:101-156) through ed_score_nll against the losses the
     reference's own collaters + losses produced (fixture scoring.npz); tolerance relative to the summed NLL."""
