@@ -638,6 +638,46 @@ def test_device_side_validation_reports_on_the_next_call(dev):
     m.check_errors()
 
 
+def test_torch_operators_equal_the_ctypes_binding(dev):
+    """torch.ops.evodiff_amd.* (evodiff_amd/csrc/torch_ops.cpp, the thin PyTorch-ROCm C++ extension of north_star) call
+    the same C ABI as the ctypes binding: results are bit-identical, errors surface as RuntimeError."""
+    from evodiff_amd import torch_ops
+    from evodiff_amd.utils import Tokenizer
+    ops = torch_ops.load()
+    oracle = R.build_model(TINY_WIDE, None, 12)
+    m = product_model(oracle, TINY_WIDE, precision="bf16")
+    h = torch_ops.handle_of(m, dev)
+    B, L = 3, 70
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.integers(0, 31, (B, L))).to(dev)
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    assert torch.equal(ops.forward(h, x, t, 31, 1), m(x, t))
+    order = torch.from_numpy(rng.permutation(L).astype(np.int32)).to(dev)
+    uni = torch.from_numpy(rng.random((L, B), dtype=np.float32)).to(dev)
+    a = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+    b = a.clone()
+    m.oadm_sample(a, order, uni, R.OADM_DRAW)
+    out = ops.oadm_sample_(h, b, order, uni, R.OADM_DRAW, 1, True)
+    assert out.data_ptr() == b.data_ptr() and torch.equal(a, b) and int((a == R.MASK_ID).sum()) == 0
+    tgt = torch.from_numpy(rng.integers(0, 21, (B, L))).to(dev)
+    assert torch.equal(ops.score_nll(h, x, t, tgt, None, 31, 1), m.score_nll(x, t, tgt))
+    with pytest.raises(RuntimeError, match="n_draw"):
+        ops.oadm_sample_(h, b, order, uni, 99, 1, True)
+    # D3PM through the operator
+    oracle = R.build_model(TINY, 500, 13)
+    m = product_model(oracle, TINY, timesteps=500, precision="fp32")
+    h = torch_ops.handle_of(m, dev)
+    tok = Tokenizer(sequences=True)
+    Qbar, Q = tok.q_random_schedule(timesteps=500)
+    Q, Qbar = Q.to(dev).double().contiguous(), Qbar.to(dev).double().contiguous()
+    uni = torch.from_numpy(rng.random((500, 2, 20), dtype=np.float32)).to(dev)
+    a = torch.from_numpy(rng.integers(0, tok.K, (2, 20))).to(dev)
+    b = a.clone()
+    m.d3pm_sample(a, Q, Qbar, uni, tok.K, t_start=499, n_steps=5)
+    ops.d3pm_sample_(h, b, Q, Qbar, uni, tok.K, 499, 5, 0, True)
+    assert torch.equal(a, b)
+
+
 def test_order_opt_sampler_against_reference_trace(golden_dir, dev):
     """generate_oaardm_order_opt (generate.py:151-177), fp32, against the trace the reference's own
     source produced: the same positions are picked and the same tokens drawn wherever neither the argmax nor the

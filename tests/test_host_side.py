@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().ed_abi_version() == 1
 
 
+def test_torch_operator_extension_registers_the_hot_path_ops():
+    """The thin PyTorch-ROCm C++ extension (north_star): torch.ops.evodiff_amd.* exist once the in-tree library is
+    loaded, and have no CPU kernel (there is no CPU path)."""
+    from evodiff_amd import torch_ops
+    ops = torch_ops.load()
+    for name in ("forward", "oadm_sample_", "d3pm_sample_", "score_nll"):
+        assert hasattr(ops, name), name
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.forward(1, torch.zeros((1, 4), dtype=torch.long), torch.zeros(1, dtype=torch.long), 31, 0)
+
+
 def test_python_option_names_match_the_header_enum():
     """evodiff_amd._lib.OPTIONS mirrors `enum { ED_OPT_* }` of include/evodiff_hip.h value for value."""
     from evodiff_amd import _lib
