@@ -46,6 +46,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_FP32_TFLOPS = 157.3
+# what a bare v_mfma_f32_16x16x32_bf16 loop on RANDOM operands sustains on this chip (the clock is held down under load;
+# tools/micro/mfma_peak.hip, profiles/r02_mfma_sustained_peak_microbench.txt); reported beside the nominal peak, never as it
+SUSTAINED_BF16_TFLOPS = 1953.0
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E
 SEED_ORDER, SEED_UNIFORM, SEED_START = 1000, 2000, 3000
 
@@ -398,7 +401,9 @@ def main():
             seq_rate = world * B * args.steps / elapsed
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                                "frac": achieved / peak, "traffic": measured_traffic(args),
-                               "kernel": "conv_window_kernel (dilated k=5 convolution, activation window resident in LDS)",
+                               "kernel": "conv_window_kernel (dilated k=5 convolution, activation window resident in LDS; since "
+                                         "round 2 it also applies the LayerNorm + GELU behind it in its epilogue, and the "
+                                         "LayerNorm launch that followed it in round 1, 15.6 us, is gone)",
                                "launches_timed": conv["launches"],
                                "avg_launch_ms": conv["ms"] / max(conv["launches"], 1),
                                "flops_per_launch": conv["flops"] / max(conv["launches"], 1)}
@@ -408,6 +413,11 @@ def main():
             # across rounds.  `frac_executed`: the FLOPs the library really launched / wall time - hardware utilisation.
             step = {"flops_per_sequence": f_eff, "achieved": f_eff * seq_rate / 1e12, "unit": "TFLOP/s",
                     "frac": f_eff * seq_rate / 1e12 / (peak * world)}
+            if args.precision == "bf16":
+                out["roofline"]["frac_of_sustained_mfma"] = achieved / SUSTAINED_BF16_TFLOPS
+                step["frac_of_sustained_mfma"] = step["achieved"] / (SUSTAINED_BF16_TFLOPS * world)
+                step["sustained_mfma_note"] = ("a bare bf16 MFMA loop on random operands sustains 1953 TFLOP/s on this chip "
+                                               "(78 % of the nominal 2500; profiles/r02_mfma_sustained_peak_microbench.txt)")
             if not d3pm:
                 exe = executed_flops_per_batch(model, torch.full((B, L), mask_id, dtype=torch.long, device=dev),
                                                orders[-1], uniforms[-1], n_draw) / B
