@@ -1218,11 +1218,18 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   if (kernel >= 3 && kernel < 100) {  // diagnostic ablations of the tuned kernel (3: no MFMAs, 4: no DMA); results are not valid
     p.ablate = kernel - 2;
     kernel = 2;
-    if (p.ablate == 7) {  // in-kernel clock stamps: four values per 256-row tile
+    if (p.ablate == 7) {  // in-kernel clock stamps: eight values per 256-row tile
       const int64_t tiles = (int64_t)B * ((L + 255) / 256) * ((N + 255) / 256);
-      if (!g_stamp_buf || g_stamp_cap < 4 * tiles) return fail(ED_EINVAL, "stamp buffer missing or too small");
+      if (!g_stamp_buf || g_stamp_cap < 8 * tiles) return fail(ED_EINVAL, "stamp buffer missing or too small");
       p.stamps = g_stamp_buf;
     }
+  }
+  if (kernel >= 500) {  // 500 + diagnostic bits: the fused-LayerNorm kernel (as 400 + bits) with in-kernel clock stamps
+    const int64_t tiles = (int64_t)B * ((L + 255) / 256) * ((N + 255) / 256);
+    if (!g_stamp_buf || g_stamp_cap < 8 * tiles) return fail(ED_EINVAL, "stamp buffer missing or too small");
+    p.stamps = g_stamp_buf;
+    p.ablate = 7;
+    kernel -= 100;
   }
   if (kernel >= 400) {  // tuned kernel with a LayerNorm + GELU (gamma = 1, beta = 0) in its epilogue; 400 + diagnostic bits
     static DevBuf dbg_ln_out, dbg_ln_stats, dbg_ln_ctr, dbg_ln_vec;

@@ -79,6 +79,8 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
+  unsigned long long r_entry = 0;
+  if constexpr (STAMP) r_entry = __builtin_amdgcn_s_memrealtime();
 
   // XCD-aware tile order (as gemm_bf16.hip)
   int tile;
@@ -223,13 +225,20 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
     }
     a_next += kc + 2 < ksteps ? ROW_B : 0;
   }
-  if constexpr (STAMP) {  // diagnostic build only: loop duration in shader cycles and in 100-MHz ticks
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  // diagnostic build only (eight values per tile): loop duration in shader cycles and in 100-MHz ticks, then the
+  // absolute 100-MHz times of entry, loop start, loop end / statistics published, and exit (stores drained)
+  unsigned long long r1 = 0;
+  if constexpr (STAMP) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      g.stamps[4 * tile] = 0;
-      g.stamps[4 * tile + 1] = (long long)(c1 - c0);
-      g.stamps[4 * tile + 2] = 0;
-      g.stamps[4 * tile + 3] = (long long)(r1 - r0);
+      g.stamps[8 * tile] = 0;
+      g.stamps[8 * tile + 1] = (long long)(c1 - c0);
+      g.stamps[8 * tile + 2] = 0;
+      g.stamps[8 * tile + 3] = (long long)(r1 - r0);
+      g.stamps[8 * tile + 4] = (long long)r_entry;
+      g.stamps[8 * tile + 5] = (long long)r0;
+      g.stamps[8 * tile + 6] = (long long)r1;
     }
   }
 
@@ -239,8 +248,15 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
   asm volatile("" : "+s"(l0e));
   if constexpr (LNF) {
     const unsigned ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, (int)threadIdx.x);
+    if constexpr (STAMP) {
+      if (tid == 0) g.stamps[8 * tile + 6] = (long long)__builtin_amdgcn_s_memrealtime();  // statistics published
+    }
     ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0,
-                      (int)threadIdx.x);
+                      (int)threadIdx.x, STAMP ? g.stamps + 8 * tile : nullptr);
+    if constexpr (STAMP) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 0) g.stamps[8 * tile + 7] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     return;
   }
 #pragma unroll
@@ -264,6 +280,10 @@ __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, in
         }
       }
     }
+  }
+  if constexpr (STAMP) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tid == 0) g.stamps[8 * tile + 7] = (long long)__builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -319,7 +339,13 @@ hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream) {
   {                                                                                                       \
     const int tiles_n = p.N / (NTV * 64);                                                                 \
     const int tiles_total = p.B * ((p.L + WMV * 64 - 1) / (WMV * 64)) * tiles_n;                          \
-    if (p.ln.gamma)                                                                                       \
+    if (p.ln.gamma && p.ablate == 7 && p.stamps) {                                                        \
+      if constexpr (NTV == 5 && WMV == 4)                                                                 \
+        hipLaunchKernelGGL((conv_window_kernel<NTV, true, true, WMV, true>), dim3(tiles_total), dim3(WMV * 128), 0, \
+                           stream, p, tiles_n, tiles_total, wp);                                          \
+      else                                                                                                \
+        return hipErrorInvalidValue;                                                                      \
+    } else if (p.ln.gamma)                                                                                \
       hipLaunchKernelGGL((conv_window_kernel<NTV, true, false, WMV, true>), dim3(tiles_total), dim3(WMV * 128), 0, \
                          stream, p, tiles_n, tiles_total, wp);                                            \
     else if (p.ablate == 7 && p.stamps)                                                                   \

@@ -58,7 +58,7 @@ template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT =
           bool LNF = false>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
   static_assert(!SPLIT || (!OUT_BF16 && !RESID && RT == 0 && ABLATE == 0), "split form: raw fp32 partial sums only");
-  static_assert(!LNF || (!SPLIT && ABLATE == 0), "fused LayerNorm: whole sums only");
+  static_assert(!LNF || (!SPLIT && (ABLATE == 0 || ABLATE == 3)), "fused LayerNorm: whole sums only");
   constexpr int BM = WM * 64;       // (shadows the file-scope 256)
   constexpr int BN = NT * 64;
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B, STAGE = A_BYTES + B_BYTES;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
-  unsigned long long sc0 = 0, sc1 = 0, sr0 = 0;
+  unsigned long long sc0 = 0, sc1 = 0, sr0 = 0, sr_loop0 = 0;
   if constexpr (ABLATE == 3) {
     sc0 = __builtin_amdgcn_s_memtime();
     sr0 = __builtin_amdgcn_s_memrealtime();
@@ -197,7 +197,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
     // of 4.  The issue order is pinned; behind each MFMA comes at most one auxiliary instruction: the read of the
     // weight fragment three groups ahead, a read of the second k-slice's activation fragments, or one of the
     // step's copies into the other stage.
-    if constexpr (ABLATE == 3) sc1 = __builtin_amdgcn_s_memtime();
+    if constexpr (ABLATE == 3) {
+      sc1 = __builtin_amdgcn_s_memtime();
+      sr_loop0 = __builtin_amdgcn_s_memrealtime();
+    }
     auto step = [&](int t) {
       const char* st = lds + (t & 1) * STAGE;
       auto read_act = [&](int s2, int ip) { fact[s2][ip] = *(const bf16x8*)(st + a_rd + ip * 16 * ROW_B + ((s2 << 6) ^ f_x)); };
@@ -277,8 +280,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
     }
   }
 
-  unsigned long long sc2 = 0;
-  if constexpr (ABLATE == 3) sc2 = __builtin_amdgcn_s_memtime();
+  unsigned long long sc2 = 0, sr_loop1 = 0;
+  if constexpr (ABLATE == 3) {
+    sc2 = __builtin_amdgcn_s_memtime();
+    sr_loop1 = __builtin_amdgcn_s_memrealtime();
+  }
   // ---- epilogue: four consecutive channels of one position per lane and accumulator.  The row base is laundered
   // through an empty asm so that the addresses are computed HERE: hoisted above the K loop as loop invariants (or
   // shared with the residual loads) they cost live registers.
@@ -286,7 +292,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   asm volatile("" : "+s"(l0e));
   unsigned ln_target = 0;
   if constexpr (LNF) ln_target = ln_publish<NT, WM>(g, acc, lds, tile_m, tile_n, tiles_n, (int)threadIdx.x);
-  if constexpr (!LNF || RESID) {
+  // (fused LayerNorm with a residual: ln_finish stores the raw sums itself, behind its wait; g.ln.dbg bit 16 keeps
+  // the older order - raw stores here, in front of the wait - for comparisons)
+  if (!LNF || (RESID && (g.ln.dbg & 16))) {
 #pragma unroll
   for (int ip = 0; ip < 4; ++ip) {
     const int l = l0e + wr * 64 + ip * 16 + fr;
@@ -312,16 +320,21 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int 
   }
   }
   if constexpr (LNF)
-    ln_finish<NT, WM>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM, n0,
-                      (int)threadIdx.x);
-  if constexpr (ABLATE == 3) {  // diagnostic build: {prologue, K loop, epilogue incl. store drain} cycles, total ticks
+    ln_finish<NT, WM, RESID>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e, g.L - l0e < BM ? g.L - l0e : BM,
+                             n0, (int)threadIdx.x);
+  if constexpr (ABLATE == 3) {  // diagnostic build (eight values per tile): {prologue, K loop, epilogue incl. store
+    // drain} cycles, total ticks, then the absolute 100-MHz times of entry, loop start, loop end and exit
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long sc3 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      g.stamps[4 * tile] = (long long)(sc1 - sc0);
-      g.stamps[4 * tile + 1] = (long long)(sc2 - sc1);
-      g.stamps[4 * tile + 2] = (long long)(sc3 - sc2);
-      g.stamps[4 * tile + 3] = (long long)(sr1 - sr0);
+      g.stamps[8 * tile] = (long long)(sc1 - sc0);
+      g.stamps[8 * tile + 1] = (long long)(sc2 - sc1);
+      g.stamps[8 * tile + 2] = (long long)(sc3 - sc2);
+      g.stamps[8 * tile + 3] = (long long)(sr1 - sr0);
+      g.stamps[8 * tile + 4] = (long long)sr0;
+      g.stamps[8 * tile + 5] = (long long)sr_loop0;
+      g.stamps[8 * tile + 6] = (long long)sr_loop1;
+      g.stamps[8 * tile + 7] = (long long)sr1;
     }
   }
 }
@@ -335,6 +348,20 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   if (p.ln.gamma) {  // LayerNorm + GELU in the epilogue
     if (!gemm_bf16_ln_supported(p) || !p.ln.beta || !p.ln.out || !p.ln.stats || !p.ln.counters || !p.ln.error)
       return hipErrorInvalidValue;
+    if (p.ablate == 7 && p.stamps) {  // diagnostic: the fused kernels of the 640M geometry with clock stamps
+      if constexpr (!CONV && NT == 5 && WM == 4) {
+        const bool whole = ((long)p.B * p.L) % BMT == 0 && (p.B == 1 || p.L % BMT == 0) && p.resid_mul == 1;
+        if (p.resid && whole && p.K == 20 * BK)
+          hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, false, true, 3, 20, WM, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+        else if (!p.resid)
+          hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, true, false, 3, 0, WM, false, true>), grid, block, 0, stream, p, tiles_n, tiles_total);
+        else
+          return hipErrorInvalidValue;
+        return hipGetLastError();
+      } else {
+        return hipErrorInvalidValue;
+      }
+    }
     if (p.resid) {
       if constexpr (!CONV) {
         const bool whole = ((long)p.B * p.L) % BMT == 0 && (p.B == 1 || p.L % BMT == 0) && p.resid_mul == 1;

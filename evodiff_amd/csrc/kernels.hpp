@@ -61,7 +61,8 @@ struct LnFuse {
   unsigned* counters = nullptr;  // one arrival counter per row tile; never reset (see ln_epilogue.hpp)
   unsigned* error = nullptr;     // host-visible word, set to 1 when a bounded wait ran out
   int dbg = 0;                   // diagnostics (ed_debug_gemm 400 + dbg; results invalid): 1 no wait for the partners, 2 no GELU,
-                                 //   4 no stores of the normalised rows, 8 no statistics pass
+                                 //   4 no stores of the normalised rows, 8 no statistics pass, 16 raw result stored in
+                                 //   front of the wait (the older order; results valid)
   // The GEMM's own result is still stored to GemmProblem::out when it has a residual (PFF2: the fp32 residual stream);
   // otherwise only the normalised rows leave the kernel.
 };
@@ -93,7 +94,7 @@ struct GemmProblem {
   int tile = 128;       // generic kernel only: 128 x 128 or 64 x 64 output tile per workgroup
   int ksplit = 1;       // generic kernel only: the K loop is cut into ksplit ranges (grid.z); range z writes its raw fp32
   float* partial = nullptr;  //   sums to partial[z][B*L][N] and launch_reduce_partials adds them up in a fixed order
-  long long* stamps = nullptr;  // diagnostics (ablate == 7): per tile {shader cycles, 100-MHz ticks} of the K loop
+  long long* stamps = nullptr;  // diagnostics (ablate == 7): eight clock stamps per tile (evodiff_hip.h, ed_debug_set_stamp_buffer)
   int ablate = 0;       // diagnostics of the tuned kernel: 1 = no MFMAs, 2 = no DMA copies (results are wrong), 3 = no window form
   int tap_center = -1;  // tap t reads position l + (t - center) * dilation; -1 = ntaps / 2 ('same' padding, MaskedConv1d),
                         //   ntaps - 1 = causal (left padding only, MaskedCausalConv1d)
@@ -120,7 +121,7 @@ hipError_t launch_gemm_bf16(const GemmProblem& p, hipStream_t stream);
 // ln_epilogue.hpp), no cut K loop, no diagnostic form.  The caller decides on the activation (GELU only).
 inline bool gemm_bf16_ln_supported(const GemmProblem& p) {
   const int tn = p.N % 320 == 0 ? p.N / 320 : p.N / 256;
-  return gemm_bf16_supported(p) && p.ksplit == 1 && p.ablate == 0 && tn >= 1 && (tn & (tn - 1)) == 0;
+  return gemm_bf16_supported(p) && p.ksplit == 1 && (p.ablate == 0 || p.ablate == 7) && tn >= 1 && (tn & (tn - 1)) == 0;
 }
 // Window-in-LDS form of the dilated convolution (conv_window.hip): five taps, dilation <= 16; launch_gemm_bf16
 // picks it by itself when the shape allows (GemmProblem::ablate == 3 keeps the per-tap form, for comparisons).

@@ -77,6 +77,15 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
   lnf32x2* const red = (lnf32x2*)lds;                 // [BM][8] lane partials {mean, M2}
+  // this tile's gamma / beta go to LDS ([2][BN] behind the row statistics): the loads fly under the statistics and
+  // ln_finish reads them at LDS latency instead of five rounds of global loads
+  constexpr int BN = NT * 64;
+  float* const gb = (float*)(lds + BM * 64 + BM * 8);
+  lnf32x4 gv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+  if (tid < BN / 4) {
+    gv = *(const lnf32x4*)(f.gamma + tile_n * BN + 4 * tid);
+    bv = *(const lnf32x4*)(f.beta + tile_n * BN + 4 * tid);
+  }
 
   // ---- 1. lane partials
 #pragma unroll
@@ -101,6 +110,10 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
     const float m = sl * (1.0f / NL);
     const float q = fmaxf(fmaf(-sl, m, q2.x + q2.y), 0.f);
     red[(wr * 64 + ip * 16 + fr) * 8 + wc * 4 + fq] = lnf32x2{m, q};
+  }
+  if (tid < BN / 4) {
+    *(lnf32x4*)(gb + 4 * tid) = gv;
+    *(lnf32x4*)(gb + BN + 4 * tid) = bv;
   }
   __syncthreads();
 
@@ -135,9 +148,14 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
   return target;
 }
 
-template <int NT, int WM, typename Acc>
+// RAW: the raw fp32 result (PFF2: the residual stream) is stored here too, to g.out, interleaved with the normalised
+// rows AFTER the wait and the statistics loads: issued in front of them (as a separate store loop between the halves)
+// the 40 16-byte stores of a lane sit in front of the poll's and the statistics' loads in the wave's memory queue,
+// and the epilogue waits for their drain twice.
+template <int NT, int WM, bool RAW = false, typename Acc>
 __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* lds, unsigned target, int tile_m,
-                                          int tiles_n, long row_base, int rows_valid, int n0, int tid_in) {
+                                          int tiles_n, long row_base, int rows_valid, int n0, int tid_in,
+                                          long long* stamp = nullptr) {  // stamp: diagnostic builds, two 100-MHz times
   constexpr int BM = WM * 64, BN = NT * 64;
   const LnFuse& f = g.ln;
   int tid = tid_in;
@@ -159,25 +177,48 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
     }
   }
   __syncthreads();
+  if (stamp && tid == 0) stamp[0] = (long long)__builtin_amdgcn_s_memrealtime();  // all partners arrived
 
   // ---- 4. whole-row statistics from the tiles_n workgroup partials (sc1 loads), fixed order
   if (tid < BM) {
     float ms = 0.f, qs = 0.f, dv = 0.f;
-    for (int w = 0; w < tiles_n; ++w) {
-      const unsigned long long bits = __hip_atomic_load(slab + (long)w * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ms += __uint_as_float((unsigned)bits);
-      qs += __uint_as_float((unsigned)(bits >> 32));
-    }
-    const float mean = ms / (float)tiles_n;
-    for (int w = 0; w < tiles_n; ++w) {
-      const unsigned long long bits = __hip_atomic_load(slab + (long)w * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float d = __uint_as_float((unsigned)bits) - mean;
-      dv = fmaf(d, d, dv);
+    float mean;
+    if (tiles_n <= 8) {  // one batch of loads in flight, one wait (same order of additions as the loop form)
+      unsigned long long bits[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        bits[w] = w < tiles_n ? __hip_atomic_load(slab + (long)w * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        if (w < tiles_n) {
+          ms += __uint_as_float((unsigned)bits[w]);
+          qs += __uint_as_float((unsigned)(bits[w] >> 32));
+        }
+      mean = ms / (float)tiles_n;
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+        if (w < tiles_n) {
+          const float d = __uint_as_float((unsigned)bits[w]) - mean;
+          dv = fmaf(d, d, dv);
+        }
+    } else {
+      for (int w = 0; w < tiles_n; ++w) {
+        const unsigned long long bits = __hip_atomic_load(slab + (long)w * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ms += __uint_as_float((unsigned)bits);
+        qs += __uint_as_float((unsigned)(bits >> 32));
+      }
+      mean = ms / (float)tiles_n;
+      for (int w = 0; w < tiles_n; ++w) {
+        const unsigned long long bits = __hip_atomic_load(slab + (long)w * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float d = __uint_as_float((unsigned)bits) - mean;
+        dv = fmaf(d, d, dv);
+      }
     }
     const float var = fmaf((float)BN, dv, qs) / (float)(BN * tiles_n);
     rowstat[tid] = lnf32x2{mean, rsqrtf(var + LN_FUSED_EPS)};
   }
   __syncthreads();
+  if (stamp && tid == 0) stamp[2] = (long long)__builtin_amdgcn_s_memrealtime();  // whole-row statistics in LDS
 
   // ---- 5. normalise, scale / shift, activate, round to bf16, store: eight consecutive channels per 16-byte store
   const int nb = n0 + wc * (BN / 2) + 8 * fq;
@@ -197,13 +238,21 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
     }
     orow[ip] = r < rows_valid ? R : -1;
   }
+  float* const raw = RAW ? (float*)g.out + (row_base + wr * 64 + fr) * g.N + nb : nullptr;
+  const float* const gb = (const float*)(lds + BM * 64 + BM * 8) + wc * (BN / 2) + 8 * fq;  // staged by ln_publish
 #pragma unroll
   for (int jp = 0; jp < NT; ++jp) {
-    const lnf32x4 g0 = *(const lnf32x4*)(f.gamma + nb + 32 * jp), g1 = *(const lnf32x4*)(f.gamma + nb + 32 * jp + 4);
-    const lnf32x4 b0 = *(const lnf32x4*)(f.beta + nb + 32 * jp), b1 = *(const lnf32x4*)(f.beta + nb + 32 * jp + 4);
+    const lnf32x4 g0 = *(const lnf32x4*)(gb + 32 * jp), g1 = *(const lnf32x4*)(gb + 32 * jp + 4);
+    const lnf32x4 b0 = *(const lnf32x4*)(gb + BN + 32 * jp), b1 = *(const lnf32x4*)(gb + BN + 32 * jp + 4);
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) {
       const lnf32x4 v = acc[2 * jp][ip], w = acc[2 * jp + 1][ip];
+      if constexpr (RAW) {
+        if (orow[ip] >= 0 && !(f.dbg & 16)) {
+          *(lnf32x4*)(raw + (long)(ip * 16) * g.N + 32 * jp) = v;
+          *(lnf32x4*)(raw + (long)(ip * 16) * g.N + 32 * jp + 4) = w;
+        }
+      }
       lnf32x2 y[4] = {{v[0], v[1]}, {v[2], v[3]}, {w[0], w[1]}, {w[2], w[3]}};
       const lnf32x2 gm[4] = {{g0[0], g0[1]}, {g0[2], g0[3]}, {g1[0], g1[1]}, {g1[2], g1[3]}};
       const lnf32x2 bt[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};

@@ -225,9 +225,11 @@ int ed_debug_gemm_splitk_noalloc(const void* A_dev, int64_t a_seq_pitch, int64_t
                                  const float* bias_dev, void* out_dev, const float* resid_dev, int B, int L, int N, int K,
                                  int ntaps, int dilation, int out_bf16, int tile, int ksplit, void* stream);
 
-/* Diagnostic hook for ed_debug_gemm(kernel = 9): a device buffer of n int64 that receives, per 256-row tile of the
- * tuned kernels, {prologue, K loop, epilogue} shader cycles and the 100-MHz ticks they span (the windowed convolution
- * stamps its K loop only: {0, loop cycles, 0, loop ticks}).  NULL detaches the buffer. */
+/* Diagnostic hook for ed_debug_gemm(kernel = 9, or 500 + bits: the fused-LayerNorm form): a device buffer of n int64
+ * that receives EIGHT values per 256-row tile of the tuned kernels: {prologue, K loop, epilogue} shader cycles and the
+ * 100-MHz ticks they span (the windowed convolution stamps its K loop only: {0, loop cycles, 0, loop ticks}), then
+ * the absolute 100-MHz times of workgroup entry, K-loop start, K-loop end (fused convolution: statistics published)
+ * and exit with the stores drained.  NULL detaches the buffer. */
 int ed_debug_set_stamp_buffer(int64_t* stamps_dev, int64_t n);
 
 /* Kernel-level test/benchmark hook (no counterpart in the reference): out = act(LayerNorm(in)) row-wise,

@@ -50,7 +50,7 @@ def main():
         stamps = torch.zeros(4 * wgs, dtype=torch.int64, device=dev)
         _lib.check(lib.ed_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()))
     elif a.kernel == 9:
-        stamps = torch.zeros(4 * B * ((L + 255) // 256) * ((a.N + 255) // 256), dtype=torch.int64, device=dev)
+        stamps = torch.zeros(8 * B * ((L + 255) // 256) * ((a.N + 255) // 256), dtype=torch.int64, device=dev)
         _lib.check(lib.ed_debug_set_stamp_buffer(stamps.data_ptr(), stamps.numel()))
     for _ in range(5):
         launch()
@@ -74,7 +74,7 @@ def main():
               f"first operands in LDS {q(st[:, 1] - t0)}, K loop done {q(st[:, 2] - t0)}, stores done {q(st[:, 3] - t0)}")
         _lib.check(lib.ed_debug_set_stamp_buffer(None, 0))
     elif stamps is not None:
-        st = stamps.view(-1, 4).cpu().double()
+        st = stamps.view(-1, 8).cpu().double()[:, :4]
         st = st[st[:, 3] > 0]
         clk = (st[:, :3].sum(1) / st[:, 3]).median().item() * 100.0
         steps = a.taps * (a.K // 64)
