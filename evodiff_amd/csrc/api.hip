@@ -1238,10 +1238,12 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
     if (!gemm_bf16_ln_supported(p)) return fail(ED_EINVAL, "kernel 400+: shape outside the fused-LayerNorm contract");
     const size_t rows = (size_t)B * ((L + 127) / 128) * 128 + 256;
     HIP_TRY(dbg_ln_out.ensure(rows * N * 2));
-    HIP_TRY(dbg_ln_stats.ensure(rows * 8 * 8));
-    if (dbg_ln_ctr.bytes < rows / 128 * 4) {
-      HIP_TRY(dbg_ln_ctr.ensure(rows / 128 * 4));
+    HIP_TRY(dbg_ln_stats.ensure(3 * rows * 8 * 8));
+    const int kind = ntaps > 1 ? 1 : resid_dev ? 2 : 0;
+    if (dbg_ln_ctr.bytes < 3 * (rows / 128) * 4) {  // one set of counters (and statistics) per kind of GEMM
+      HIP_TRY(dbg_ln_ctr.ensure(3 * (rows / 128) * 4));
       HIP_TRY(hipMemsetAsync(dbg_ln_ctr.p, 0, dbg_ln_ctr.bytes, s));
+      HIP_TRY(hipStreamSynchronize(s));
     }
     if (dbg_ln_vec.bytes < (size_t)N * 8) {
       HIP_TRY(dbg_ln_vec.ensure((size_t)N * 8));
@@ -1257,8 +1259,8 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
     p.ln.gamma = dbg_ln_vec.as<float>();
     p.ln.beta = dbg_ln_vec.as<float>() + N;
     p.ln.out = dbg_ln_out.as<bf16_t>();
-    p.ln.stats = dbg_ln_stats.p;
-    p.ln.counters = dbg_ln_ctr.as<unsigned>();
+    p.ln.stats = (char*)dbg_ln_stats.p + (size_t)kind * rows * 8 * 8;
+    p.ln.counters = dbg_ln_ctr.as<unsigned>() + (size_t)kind * (rows / 128);
     p.ln.error = dbg_err_dev;
     p.ln.dbg = kernel - 400;
     LAUNCH_TRY(launch_gemm_bf16(p, s));

@@ -1,0 +1,82 @@
+// In-launch hand-off between the phases of a block chain (block_chain.hip): PFF1 -> convolution -> PFF2 of one or more
+// ByteNet blocks run as ONE persistent launch, each workgroup keeping its (row tile, column tile) through all phases.
+//
+// Why: between two launches a CU sits idle from the exit of its workgroup to the first MFMA of the next one - 3.5-4.5 us
+// until the next launch's workgroup enters (dispatch, LDS and register allocation; measured with in-kernel clocks,
+// tools/kernel_timeline.py; two streams feeding the CUs without any ordering do not shorten it), ~3 us of prologue
+// until the first operands are in LDS, and the launch ends with its slowest XCD.  A phase change inside a launch costs
+// the hand-off below instead.
+//
+// What is handed over: a phase's A operand rows of a row tile are the normalised rows the tiles_n workgroups of that
+// SAME row tile stored in the phase before (1x1 projections are row-local; the convolution is when a row tile is a whole
+// sequence, which is what the launcher checks).  Protocol (cdna_hip_programming.md Guideline 16; MI355X_MICROARCH.md
+// "Valid forms": write-through stores, every storing wave drained, one signalling lane behind a workgroup barrier;
+// consumer: one relaxed poll, ONE agent acquire, wait, barrier, then plain loads / LDS-DMA copies):
+//   producer: the normalised rows leave as write-through (sc1) 16-byte stores; every wave `s_waitcnt vmcnt(0)`;
+//             workgroup barrier; ONE lane adds 1 to the row tile's chain counter (agent-scope atomic);
+//   consumer: ONE lane polls that counter (relaxed, agent scope, bounded) until phase_index * tiles_n arrivals are in;
+//             its wave runs the agent acquire (buffer_inv sc1: this CU's L1 holds lines of the same buffers from the
+//             block before) and waits for it; workgroup barrier; only then the first copy of the phase's A operand is
+//             issued.  The weights' first copies are issued BEFORE the wait - they depend on nothing.
+// Counters are zero between launches: the arrival that completes the last phase of a launch stores 0 (every wait on the
+// counter has been satisfied by then).  Nothing is assumed about dispatch order or workgroup -> XCD placement; what IS
+// assumed is that all workgroups of the launch are resident at once (grid <= number of CUs, one workgroup per CU by its
+// LDS), which the launcher checks - a workgroup that waits keeps its CU.
+#pragma once
+#include "kernels.hpp"
+
+namespace ed {
+
+struct ChainCtl {
+  unsigned* ctr = nullptr;     // one counter per row tile
+  unsigned* error = nullptr;   // host-visible word (ED_AERR_LN_WAIT slot), set when a bounded wait runs out
+  unsigned wait_target = 0;    // arrivals that must be in before the phase's A operand may be read (0: none)
+  unsigned final_total = 0;    // > 0: this is the launch's last phase; the arrival that makes the counter this resets it
+};
+
+constexpr unsigned long long CHAIN_SPIN_TICKS = 5000000ull;  // 50 ms of the 100-MHz clock
+
+// Called by ALL threads of the workgroup, after the phase's weight copies were issued and before its first A copy.
+__device__ __forceinline__ void chain_wait(const ChainCtl& cc, int tile_m, int tid) {
+  if (cc.wait_target == 0) return;  // (uniform)
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (tid < 64) {
+    if (tid == 0) {
+      gu32* const c = (gu32*)cc.ctr + tile_m;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cc.wait_target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > CHAIN_SPIN_TICKS) {  // a partner never arrived: report, do not hang
+          __hip_atomic_store((gu32*)cc.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the polling wave, after its poll matched
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the invalidate completes asynchronously)
+  }
+  __syncthreads();
+}
+
+// Called by ALL threads after the phase's last store.
+__device__ __forceinline__ void chain_signal(const ChainCtl& cc, int tile_m, int tid) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the signalling lane joins
+  __syncthreads();
+  if (tid == 0) {
+    gu32* const c = (gu32*)cc.ctr + tile_m;
+    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cc.final_total && old + 1 == cc.final_total) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// 16-byte write-through store (the chain's hand-off data)
+template <typename V>
+__device__ __forceinline__ void store16_wt(void* p, V v) {
+  static_assert(sizeof(V) == 16, "16-byte vector");
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 bits = __builtin_bit_cast(u32x4, v);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(bits) : "memory");
+}
+
+}  // namespace ed

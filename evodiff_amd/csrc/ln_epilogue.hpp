@@ -27,6 +27,7 @@
 // statistics it has - wrong results with a reported error instead of a hung GPU.
 #pragma once
 #include "kernels.hpp"
+#include "chain.hpp"
 
 namespace ed {
 
@@ -152,7 +153,8 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
 // rows AFTER the wait and the statistics loads: issued in front of them (as a separate store loop between the halves)
 // the 40 16-byte stores of a lane sit in front of the poll's and the statistics' loads in the wave's memory queue,
 // and the epilogue waits for their drain twice.
-template <int NT, int WM, bool RAW = false, typename Acc>
+// WT: the normalised rows leave as write-through stores (block chain: they are handed to other workgroups of the launch).
+template <int NT, int WM, bool RAW = false, bool WT = false, typename Acc>
 __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* lds, unsigned target, int tile_m,
                                           int tiles_n, long row_base, int rows_valid, int n0, int tid_in,
                                           long long* stamp = nullptr) {  // stamp: diagnostic builds, two 100-MHz times
@@ -264,7 +266,8 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
       if (orow[ip] >= 0 && !(f.dbg & 4)) {
         const lnbf16x8 pk = {(__bf16)y[0].x, (__bf16)y[0].y, (__bf16)y[1].x, (__bf16)y[1].y,
                              (__bf16)y[2].x, (__bf16)y[2].y, (__bf16)y[3].x, (__bf16)y[3].y};
-        *(lnbf16x8*)(f.out + orow[ip] * g.N + nb + 32 * jp) = pk;
+        if constexpr (WT) store16_wt(f.out + orow[ip] * g.N + nb + 32 * jp, pk);
+        else *(lnbf16x8*)(f.out + orow[ip] * g.N + nb + 32 * jp) = pk;
       }
     }
   }

@@ -20,7 +20,7 @@ from evodiff_amd import _lib  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    for name, default in (("B", 64), ("L", 256), ("C", 1280), ("iters", 20), ("unfused", 0), ("dil", 1), ("dbg", 0), ("xcd", 0)):
+    for name, default in (("B", 64), ("L", 256), ("C", 1280), ("iters", 20), ("unfused", 0), ("dil", 1), ("dbg", 0), ("xcd", 0), ("streams", 1)):
         ap.add_argument("--" + name, type=int, default=default)
     a = ap.parse_args()
     lib = _lib.load()
@@ -42,26 +42,35 @@ def main():
     out16 = torch.empty((B * L, C), dtype=torch.bfloat16, device=dev)
     out32 = torch.empty((B * L, C), dtype=torch.float32, device=dev)
     resid = torch.rand((B * L, C), device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # --streams 2: consecutive launches alternate between two streams with nothing ordering them (timing experiment:
+    # how much of a launch's tail, the gap behind it and the next prologue would overlap; the data are independent here)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(a.streams - 1)]
+    turn = [0]
+
+    def next_stream():
+        turn[0] += 1
+        return streams[turn[0] % len(streams)].cuda_stream
     tiles = B * ((L + 255) // 256) * ((C + 255) // 256)
     kern = 9 if a.unfused else 500 + a.dbg  # dbg: diagnostic bits of the fused epilogue (ln_epilogue.hpp)
 
     def pff1():
         _lib.check(lib.ed_debug_gemm(A1.data_ptr(), L, 0, W1.data_ptr(), bias.data_ptr(), out16.data_ptr(), None,
-                                     B, L, C, C, 1, 1, 1, 1, kern, stream))
+                                     B, L, C, C, 1, 1, 1, 1, kern, next_stream()))
 
     def conv():
         _lib.check(lib.ed_debug_gemm(Ac.data_ptr(), pitch, halo, Wc.data_ptr(), bias.data_ptr(), out16.data_ptr(), None,
-                                     B, L, C, C, 5, a.dil, 1, 1, kern, stream))
+                                     B, L, C, C, 5, a.dil, 1, 1, kern, next_stream()))
 
     def pff2():
         _lib.check(lib.ed_debug_gemm(A1.data_ptr(), L, 0, W2.data_ptr(), bias.data_ptr(), out32.data_ptr(),
-                                     resid.data_ptr(), B, L, C, C, 1, 1, 1, 0, kern, stream))
+                                     resid.data_ptr(), B, L, C, C, 1, 1, 1, 0, kern, next_stream()))
 
     names = ["PFF1", "conv", "PFF2", "PFF1'"]
     fns = [pff1, conv, pff2, pff1]
     bufs = [torch.zeros(8 * tiles, dtype=torch.int64, device=dev) for _ in range(5)]
     _lib.check(lib.ed_debug_set_stamp_buffer(bufs[4].data_ptr(), bufs[4].numel()))
+    pff1(); conv(); pff2()      # (first calls allocate the diagnostic buffers)
+    torch.cuda.synchronize()
     for _ in range(a.iters):
         pff1(); conv(); pff2()
     for i, fn in enumerate(fns):
