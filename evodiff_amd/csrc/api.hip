@@ -123,6 +123,11 @@ struct ed_model {
   // partial statistics, arrival counters (one array per GEMM of the block: a counter must always see the same number of
   // column tiles), and a host-visible error word the kernels raise when a bounded wait runs out.
   bool fuse_ln = true;
+  // Block chain (ED_OPT_BLOCK_CHAIN, block_chain.hip): PFF1 -> convolution -> PFF2 of up to this many consecutive blocks
+  // run as one persistent launch when their shapes allow (0 = one launch per GEMM).
+  int chain_blocks = 0;
+  int n_cus = 0;      // CUs of the model's device (a chain launch needs all its workgroups resident at once)
+  DevBuf chain_ctr;   // one counter per row tile, zero between launches
   DevBuf Abuf1, ln_stats, ln_counters;
   long ln_counter_pitch = 0;
   unsigned* ln_err_host = nullptr;  // ED_AERR_WORDS host-visible words the kernels raise (kernels.hpp), checked by the
@@ -468,6 +473,11 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
       HIP_TRY(hipMemsetAsync(m->ln_counters.p, 0, m->ln_counters.bytes, s));  // zero once; launches keep them consistent
     }
     m->ln_counter_pitch = (long)(m->ln_counters.bytes / 12);
+    if (n_ctr * 4 > m->chain_ctr.bytes) {
+      HIP_TRY(need(m->chain_ctr, n_ctr * 4));
+      HIP_TRY(hipMemsetAsync(m->chain_ctr.p, 0, m->chain_ctr.bytes, s));  // zero once; every chain launch leaves them zero
+    }
+    if (!m->n_cus) HIP_TRY(hipDeviceGetAttribute(&m->n_cus, hipDeviceAttributeMultiprocessorCount, m->device));
   }
   // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
   m->n_inc = 0;
@@ -574,9 +584,19 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
   // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
   const bool y_bf16 = h;
   bool ln1_done = false;  // the previous block's PFF2 reduction already ran this block's first LayerNorm
+  // blocks collected for one chain launch (ED_OPT_BLOCK_CHAIN); flushed when full or when a block does not qualify
+  ChainBlock chain[CHAIN_MAX_BLOCKS];
+  int n_chain = 0;
+  auto flush_chain = [&]() -> int {
+    if (n_chain == 0) return ED_OK;
+    LAUNCH_TRY(launch_block_chain(chain, n_chain, m->chain_ctr.as<unsigned>(), m->ln_err_dev + ED_AERR_LN_WAIT, s));
+    n_chain = 0;
+    return ED_OK;
+  };
   for (int i = 0; i < c.n_layers; ++i) {
     int rc;
     if (variant == STEP_INCR && i < n_inc) {
+      if ((rc = flush_chain())) return rc;
       if ((rc = run_incremental_layer(m, i, B, L, prec, s))) return rc;
       continue;
     }
@@ -595,6 +615,31 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     } else if (i == n_inc && n_inc > 0) {
       x_src = m->Xc[i].as<float>();
     }
+    // Block chain: a block at every position whose three GEMMs all apply the LayerNorm behind them joins the pending
+    // chain launch (not while the probe times single launches or the per-layer activations are collected)
+    if (m->chain_blocks > 0 && h && !acts && !m->probing_now && pl.s_in == 1 && pl.s_out == 1 && i + 1 < c.n_layers &&
+        m->chain_ctr.p) {
+      ChainBlock cb;
+      cb.g1 = GemmProblem{A1, rows_in, 0, (const void*)w.w1_h, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, true, true};
+      cb.gc = GemmProblem{cpad, m->conv_pitch, m->conv_row0, (const void*)w.wc_h, w.bc, Y, nullptr, B, L, H, H, c.kernel_size,
+                          w.dilation, true, true};
+      cb.gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
+      cb.g2 = GemmProblem{A, rows_out, 0, (const void*)w.w2_h, w.b2, x_dst, x_src, 1, rows_out, D, H, 1, 1, true, false};
+      const LayerW& wn = m->layers[i + 1];
+      if (fuse_ln_into(m, cb.g1, 0, w.ln2_g, w.ln2_b, cpad, L, m->conv_pitch, m->conv_row0) &&
+          fuse_ln_into(m, cb.gc, 1, w.ln3_g, w.ln3_b, A, 0, 0, 0) &&
+          fuse_ln_into(m, cb.g2, 2, wn.ln1_g, wn.ln1_b, A1, 0, 0, 0) && block_chain_supported(cb, m->n_cus)) {
+        if (!ln1_done) {  // (only ever the first block of a chain: the blocks behind it get their input from PFF2)
+          if ((rc = flush_chain())) return rc;
+          if ((rc = run_ln(m, x_src, false, A1, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+        }
+        chain[n_chain++] = cb;
+        ln1_done = true;
+        if (n_chain == std::min(m->chain_blocks, CHAIN_MAX_BLOCKS) && (rc = flush_chain())) return rc;
+        continue;
+      }
+    }
+    if ((rc = flush_chain())) return rc;
     // the 1x1 projections are row-independent: tile them over all rows as one long sequence
     if (!ln1_done && (rc = run_ln(m, x_src, false, A1, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
     ln1_done = false;
@@ -662,6 +707,10 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     }
     if (acts)
       HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows_out * D, Xc, (size_t)rows_out * D * 4, hipMemcpyDeviceToDevice, s));
+  }
+  {
+    int rc;
+    if ((rc = flush_chain())) return rc;
   }
   if (x_out) *x_out = Xc;
   return ED_OK;
@@ -1401,6 +1450,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_FUSE_LN:
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_LN takes 0 or 1");
       m->fuse_ln = value != 0;
+      break;
+    case ED_OPT_BLOCK_CHAIN:
+      if (value < 0 || value > CHAIN_MAX_BLOCKS) return fail(ED_EINVAL, "ED_OPT_BLOCK_CHAIN must be in [0, %d]", CHAIN_MAX_BLOCKS);
+      m->chain_blocks = value;
       break;
     case ED_OPT_SPLIT_MIN_ITERS:
       if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");

@@ -34,6 +34,11 @@ struct ChainCtl {
   unsigned final_total = 0;    // > 0: this is the launch's last phase; the arrival that makes the counter this resets it
 };
 
+// cache-policy bits of the LDS-DMA copies of a chain phase's A operand (experiment: 17 = sc0 sc1)
+#ifndef ED_CHAIN_A_AUX
+#define ED_CHAIN_A_AUX 0
+#endif
+constexpr int CHAIN_A_AUX = ED_CHAIN_A_AUX;
 constexpr unsigned long long CHAIN_SPIN_TICKS = 5000000ull;  // 50 ms of the 100-MHz clock
 
 // Called by ALL threads of the workgroup, after the phase's weight copies were issued and before its first A copy.
@@ -52,6 +57,9 @@ __device__ __forceinline__ void chain_wait(const ChainCtl& cc, int tile_m, int t
         }
       }
     }
+#ifdef ED_CHAIN_DELAY
+    for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(127);  // (diagnostic: ~20 us)
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the polling wave, after its poll matched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the invalidate completes asynchronously)
   }
@@ -64,19 +72,32 @@ __device__ __forceinline__ void chain_signal(const ChainCtl& cc, int tile_m, int
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the signalling lane joins
   __syncthreads();
   if (tid == 0) {
+#ifdef ED_CHAIN_PLAIN_STORES
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     gu32* const c = (gu32*)cc.ctr + tile_m;
     const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cc.final_total && old + 1 == cc.final_total) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// 16-byte write-through store (the chain's hand-off data)
+// 16-byte write-through (sc1) stores of the chain's hand-off data, as buffer stores off a resource built once per
+// epilogue: base pointer in SGPRs, 32-bit byte offset per lane.  (A hand-written `global_store_dwordx4 ... sc1` in
+// inline asm stored wrong rows here - the compiler's hazard handling does not see inside it; the builtin is tracked like
+// any other store.)
+struct WtBuffer {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ WtBuffer wt_buffer(void* base) {
+  // raw buffer (stride 0), no bounds (the callers' offsets are in range by construction); dword 3 as for gfx90a / gfx94x / gfx950
+  return WtBuffer{__builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000)};
+}
 template <typename V>
-__device__ __forceinline__ void store16_wt(void* p, V v) {
+__device__ __forceinline__ void store16_wt(const WtBuffer& b, unsigned byte_offset, V v) {
   static_assert(sizeof(V) == 16, "16-byte vector");
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  const u32x4 bits = __builtin_bit_cast(u32x4, v);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(bits) : "memory");
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b.rsrc, (int)byte_offset, 0, /*aux: sc1*/ 16);
 }
 
 }  // namespace ed

@@ -45,9 +45,10 @@ constexpr int SEQ_ROWS = 256, BK = 64, ROW_B = BK * 2;
 constexpr int WIN_ROWS = 320, WIN_BYTES = WIN_ROWS * ROW_B;
 constexpr int NTAPS = 5;
 
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
 }
 
 constexpr int lds_bytes(int nt) { return 2 * WIN_BYTES + 2 * nt * 64 * ROW_B; }
@@ -77,6 +78,12 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   static_assert(NGB + 3 < NGRP, "copy slots of a step");
   char* const lds_w = lds + 2 * WIN_BYTES;
 
+  // Chain phase: first of all the wait for the producers of this row tile's window (see gemm_bf16_tile.hpp)
+  if constexpr (CHAIN) {
+    const int q = tiles_total >> 3, r = tiles_total & 7, x = bid_x & 7;
+    const int tile0 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid_x >> 3);
+    chain_wait(cc, tile0 / tiles_n, (int)threadIdx.x);
+  }
   int tid_raw = threadIdx.x;
   if constexpr (CHAIN) asm volatile("" : "+v"(tid_raw));  // each phase of a chain forms its lane indices afresh: shared
                                                           // with the other phases they would stay live across every K loop
@@ -117,7 +124,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
 
   auto copy_window_group = [&](int ga_raw, char* win) {  // groups past the window re-copy its last one
     const int ga = ga_raw < win_groups ? ga_raw : win_groups - 1;
-    glds16(a_next + (unsigned)ga * grp_bytes + ((ga & 1) ? lane_off1 : lane_off0), win + ga * 1024);
+    glds16<CHAIN ? CHAIN_A_AUX : 0>(a_next + (unsigned)ga * grp_bytes + ((ga & 1) ? lane_off1 : lane_off0), win + ga * 1024);
   };
   auto copy_weight_group = [&](int jj, char* wst) {
     const int grp = wid * NGB + jj;  // LDS rows 8*grp .. +7 <- channels c0 + {0..3, 8..11}
@@ -137,7 +144,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   f32x4 acc[NJ][4];
 #pragma unroll
   for (int jn = 0; jn < NJ; ++jn) {
-    const f32x4 bj = *(const f32x4*)(g.bias + nb + 32 * (jn >> 1) + 4 * (jn & 1));
+    const f32x4 bj = *(const f32x4*)(as_global(g.bias) + nb + 32 * (jn >> 1) + 4 * (jn & 1));
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) acc[jn][ip] = bj;
   }
@@ -150,18 +157,10 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
 
   // prologue: window of slice 0 and weights of step 0
   {
-    if constexpr (CHAIN) {  // the weights first, the window once its producers have signalled
 #pragma unroll
-      for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, lds_w);
-      chain_wait(cc, tile_m, tid);
+    for (int k = 0; k < WIN_ROWS / (8 * NW); ++k) copy_window_group(k * NW + wid, lds);
 #pragma unroll
-      for (int k = 0; k < WIN_ROWS / (8 * NW); ++k) copy_window_group(k * NW + wid, lds);
-    } else {
-#pragma unroll
-      for (int k = 0; k < WIN_ROWS / (8 * NW); ++k) copy_window_group(k * NW + wid, lds);
-#pragma unroll
-      for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, lds_w);
-    }
+    for (int jj = 0; jj < NGB; ++jj) copy_weight_group(jj, lds_w);
     w_dma += ntaps > 1 ? w_tap_step : w_wrap_step;
     a_next += ksteps > 1 ? ROW_B : 0;
     __syncthreads();
@@ -287,10 +286,10 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
           pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
           pk.z = (unsigned)f32_to_bf16_bits(w[0]) | ((unsigned)f32_to_bf16_bits(w[1]) << 16);
           pk.w = (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16);
-          *(uint4*)((bf16_t*)g.out + o + 32 * jp) = pk;
+          *(uint4*)(as_global((bf16_t*)g.out) + o + 32 * jp) = pk;
         } else {
-          *(f32x4*)((float*)g.out + o + 32 * jp) = v;
-          *(f32x4*)((float*)g.out + o + 32 * jp + 4) = w;
+          *(f32x4*)(as_global((float*)g.out) + o + 32 * jp) = v;
+          *(f32x4*)(as_global((float*)g.out) + o + 32 * jp + 4) = w;
         }
       }
     }

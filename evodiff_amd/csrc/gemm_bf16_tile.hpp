@@ -43,9 +43,10 @@ namespace gemm_tile {
 
 constexpr int BM = 256, BK = 64, ROW_B = BK * 2;  // 128 bytes of K per tile row per step
 
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
 }
 
 constexpr int lds_bytes(int nt, int wm) { return 2 * (wm * 64 + nt * 64) * ROW_B; }
@@ -81,6 +82,14 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   constexpr int RING = 4;           // weight fragments in flight
   static_assert(NGRP % RING == 0 && N_DMA < NGRP, "step schedule");
 
+  // Chain phase: first of all the wait for the producers of this row tile's A rows.  (Placed behind the first weight
+  // copies - which depend on nothing - it would hide ~1 us more, but any barrier between the address set-up and the K
+  // loop costs the register allocator 21 more spilled registers inside the unrolled loop.)
+  if constexpr (CHAIN) {
+    const int q = tiles_total >> 3, r = tiles_total & 7, x = bid_x & 7;
+    const int tile0 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid_x >> 3);
+    chain_wait(cc, tile0 / tiles_n, (int)threadIdx.x);
+  }
   int tid_raw = threadIdx.x;
   if constexpr (CHAIN) asm volatile("" : "+v"(tid_raw));  // each phase of a chain forms its lane indices afresh: shared
                                                           // with the other phases they would stay live across every K loop
@@ -142,7 +151,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
     if constexpr (ABLATE == 2) return;
     char* st = lds + (dma_t & 1) * STAGE;
     if (j < 4) {  // A rows wid*32 + 8j .. +8   (group wid*4 + j, parity j & 1)
-      glds16(a_dma + (unsigned)j * grp_bytes + ((j & 1) ? lane_off1 : lane_off0), st + (wid * 4 + j) * 1024);
+      glds16<CHAIN ? CHAIN_A_AUX : 0>(a_dma + (unsigned)j * grp_bytes + ((j & 1) ? lane_off1 : lane_off0), st + (wid * 4 + j) * 1024);
     } else {      // W rows n0 + 8*(wid*NGB + jj) .. +8
       const int jj = j - 4, grp = wid * NGB + jj;  // LDS rows 8*grp .. +7 <- channels c0 + {0..3, 8..11} (see below)
       const int c0 = 32 * (grp >> 2) + 16 * (grp & 1) + 4 * ((grp >> 1) & 1);
@@ -177,7 +186,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
 #pragma unroll
   for (int jn = 0; jn < NJ; ++jn) {
     f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (!SPLIT) bj = *(const f32x4*)(g.bias + nb + 32 * (jn >> 1) + 4 * (jn & 1));
+    if constexpr (!SPLIT) bj = *(const f32x4*)(as_global(g.bias) + nb + 32 * (jn >> 1) + 4 * (jn & 1));
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) acc[jn][ip] = bj;
   }
@@ -186,7 +195,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
     for (int ip = 0; ip < 4; ++ip) {
       const int l = l0 + wr * 64 + ip * 16 + fr;
       if (full_rows || l < g.L) {
-        const float* pr = g.resid + (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + nb;
+        const float* pr = as_global(g.resid) + (((long)b * g.L + l) * g.resid_mul + rsel) * g.N + nb;
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn) acc[jn][ip] += *(const f32x4*)(pr + 32 * (jn >> 1) + 4 * (jn & 1));
       }
@@ -201,17 +210,9 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   bf16x8 fact[2][4], fw[RING];  // activation fragments [k-slice][position tile]; ring of weight fragments
 
   if (T > 0) {
-    // prologue: copy of step 0 (chain phase: the weights first, the A rows once their producers have signalled)
-    if constexpr (CHAIN) {
+    // prologue: copy of step 0
 #pragma unroll
-      for (int j = 4; j < N_DMA; ++j) dma_piece(j);
-      chain_wait(cc, tile_m, tid);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dma_piece(j);
-    } else {
-#pragma unroll
-      for (int j = 0; j < N_DMA; ++j) dma_piece(j);
-    }
+    for (int j = 0; j < N_DMA; ++j) dma_piece(j);
     dma_advance();
     __syncthreads();  // (its fence drains the DMA)
 
@@ -272,16 +273,20 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
       static_assert(NG <= RT, "K loop too short to hide the residual tile");
       // wave-uniform base + one 32-bit per-lane offset: the loads then need no per-piece address registers
       // (the launcher only picks this form for resid_mul == 1: residual row == output row)
-      const float* rbase = g.resid + ((long)b * g.L + l0 + wr * 64) * g.N + n0 + wc * (BN / 2);
+      const float* rbase = as_global(g.resid) + ((long)b * g.L + l0 + wr * 64) * g.N + n0 + wc * (BN / 2);
       const unsigned rlane = (unsigned)(fr * g.N + 8 * fq);
       f32x4 rv[APG];
       auto load_group = [&](int grp) {
-        const float* rb = rbase;
-        asm volatile("" : "+s"(rb));  // addresses formed here, step by step, not hoisted out of the unrolled loop
+        const float* rb0 = rbase;
+        asm volatile("" : "+s"(rb0));  // addresses formed here, step by step, not hoisted out of the unrolled loop
+        // (typed as a global pointer: scalar base + lane offset in the load instruction itself; as a generic pointer
+        // every piece takes a 64-bit address in VGPRs)
+        const __attribute__((address_space(1))) float* const rb = (const __attribute__((address_space(1))) float*)rb0;
 #pragma unroll
         for (int v = 0; v < APG; ++v) {
           const int e = grp * APG + v, jn = e >> 2, ip = e & 3;  // accumulator (jn, ip)
-          if (e < NACC) rv[v] = *(const f32x4*)(rb + (long)(ip * 16) * g.N + 32 * (jn >> 1) + 4 * (jn & 1) + rlane);
+          if (e < NACC)
+            rv[v] = *(const __attribute__((address_space(1))) f32x4*)(rb + (long)(ip * 16) * g.N + 32 * (jn >> 1) + 4 * (jn & 1) + rlane);
         }
       };
       load_group(0);
@@ -331,9 +336,9 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
           pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
           pk.z = (unsigned)f32_to_bf16_bits(w[0]) | ((unsigned)f32_to_bf16_bits(w[1]) << 16);
           pk.w = (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16);
-          *(uint4*)((bf16_t*)g.out + o + 32 * jp) = pk;
+          *(uint4*)(as_global((bf16_t*)g.out) + o + 32 * jp) = pk;
         } else {
-          float* const outf = SPLIT ? g.partial + (long)bid_y * g.B * g.L * g.N : (float*)g.out;
+          float* const outf = as_global(SPLIT ? g.partial + (long)bid_y * g.B * g.L * g.N : (float*)g.out);
           *(f32x4*)(outf + o + 32 * jp) = v;
           *(f32x4*)(outf + o + 32 * jp + 4) = w;
         }

@@ -50,6 +50,17 @@ struct PosBit {
   }
 };
 
+// A pointer read from a structure in memory is a generic ("flat") pointer to the compiler; the tile bodies mark the
+// device-memory pointers of a problem as global ones, so that loads and stores through them keep the scalar-base +
+// lane-offset addressing of global_load / global_store (pointers that arrive as kernel arguments already have it; the
+// block chain reads its problems through a laundered pointer and lost it: 40 flat loads and 28 spilled registers).
+#if defined(__HIPCC__)
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+#endif
+
 // LayerNorm + GELU of a GEMM's result fused into the tuned kernels' epilogue (ln_epilogue.hpp).  gamma == nullptr: off.
 struct LnFuse {
   const float* gamma = nullptr;  // [N] of the LayerNorm that consumes this GEMM's result

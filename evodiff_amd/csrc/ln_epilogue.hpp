@@ -84,8 +84,8 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
   float* const gb = (float*)(lds + BM * 64 + BM * 8);
   lnf32x4 gv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
   if (tid < BN / 4) {
-    gv = *(const lnf32x4*)(f.gamma + tile_n * BN + 4 * tid);
-    bv = *(const lnf32x4*)(f.beta + tile_n * BN + 4 * tid);
+    gv = *(const lnf32x4*)(as_global(f.gamma) + tile_n * BN + 4 * tid);
+    bv = *(const lnf32x4*)(as_global(f.beta) + tile_n * BN + 4 * tid);
   }
 
   // ---- 1. lane partials
@@ -240,7 +240,8 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
     }
     orow[ip] = r < rows_valid ? R : -1;
   }
-  float* const raw = RAW ? (float*)g.out + (row_base + wr * 64 + fr) * g.N + nb : nullptr;
+  float* const raw = RAW ? as_global((float*)g.out) + (row_base + wr * 64 + fr) * g.N + nb : nullptr;
+  const WtBuffer wt = wt_buffer(WT ? (void*)f.out : nullptr);  // (offsets below 2^32 bytes: the chain's launcher checks)
   const float* const gb = (const float*)(lds + BM * 64 + BM * 8) + wc * (BN / 2) + 8 * fq;  // staged by ln_publish
 #pragma unroll
   for (int jp = 0; jp < NT; ++jp) {
@@ -266,8 +267,13 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
       if (orow[ip] >= 0 && !(f.dbg & 4)) {
         const lnbf16x8 pk = {(__bf16)y[0].x, (__bf16)y[0].y, (__bf16)y[1].x, (__bf16)y[1].y,
                              (__bf16)y[2].x, (__bf16)y[2].y, (__bf16)y[3].x, (__bf16)y[3].y};
-        if constexpr (WT) store16_wt(f.out + orow[ip] * g.N + nb + 32 * jp, pk);
-        else *(lnbf16x8*)(f.out + orow[ip] * g.N + nb + 32 * jp) = pk;
+#ifdef ED_CHAIN_PLAIN_STORES
+        if constexpr (false) {
+        }
+#else
+        if constexpr (WT) store16_wt(wt, (unsigned)((orow[ip] * g.N + nb + 32 * jp) * 2), pk);
+#endif
+        else *(lnbf16x8*)(as_global(f.out) + orow[ip] * g.N + nb + 32 * jp) = pk;
       }
     }
   }

@@ -29,6 +29,7 @@ MID = dict(d_embed=8, d_model=384, n_layers=10, kernel_size=5, r=128, slim=True,
 # shapes the tuned bf16 kernel takes: N in {256, 512} (BN=256) and N = 640 (BN=320)
 BIG512 = dict(d_embed=8, d_model=512, n_layers=9, kernel_size=5, r=128, slim=True, activation="gelu")
 BIG640 = dict(d_embed=8, d_model=640, n_layers=8, kernel_size=5, r=128, slim=False, activation="gelu")
+WIDE1280 = dict(d_embed=8, d_model=1280, n_layers=10, kernel_size=5, r=128, slim=False, activation="gelu")  # 640M's block
 
 
 @pytest.fixture(scope="module")
@@ -831,6 +832,42 @@ def test_autoregressive_sampler_vs_oracle(dev, base, precision, max_len):
     with pytest.raises(Exception, match="causal"):
         product_model(R.build_model(dict(base, n_tokens=30), None, 41), dict(base, n_tokens=30)).ar_sample(
             again, uni.t().contiguous().to(dev), n_steps=max_len)
+
+
+def test_block_chain_is_bit_identical_to_single_launches(dev):
+    """ED_OPT_BLOCK_CHAIN: PFF1 -> convolution -> PFF2 of 1, 2 or 3 consecutive blocks as ONE persistent launch whose
+    workgroups hand their rows over inside the launch (chain.hpp).  Same kernels' tile bodies, same arithmetic: logits and
+    sampled tokens must equal the one-launch-per-GEMM path BIT FOR BIT, every time (a stale or early read of a
+    handed-over row would show as a difference), eager and under graph replay; and both stay within the bf16 tolerance
+    of the oracle.  Geometry: the 640M block (d_model = d_hidden = 1280), 64 sequences of 256 positions = one tile per
+    CU, all eight dilations (windowed and whole-sequence forms of the convolution)."""
+    cfg, B, L = WIDE1280, 64, 256
+    oracle = R.build_model(cfg, None, 77)
+    m = product_model(oracle, cfg, precision="bf16")
+    x = torch.from_numpy(np.random.default_rng(5).integers(0, 31, (B, L)))
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    m.set_option("block_chain", 0)
+    single = m(x.to(dev), t).cpu().numpy()
+    with torch.no_grad():
+        ref = oracle(x[:4], torch.zeros(4, dtype=torch.long)).numpy()
+    assert rel_err(single[:4], ref) < BF16_TOL
+    n = 12
+    order = torch.from_numpy(np.random.default_rng(L).permutation(L)[:n].astype(np.int32))
+    uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32)).to(dev)
+
+    def sample_tokens(use_graph):
+        m.use_graph = use_graph
+        sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+        m.oadm_sample(sample, order, uni, R.OADM_DRAW)
+        return sample.cpu().numpy()
+
+    tokens_single = sample_tokens(True)
+    for blocks in (1, 2, 3):
+        m.set_option("block_chain", blocks)
+        for _ in range(3):
+            assert np.array_equal(m(x.to(dev), t).cpu().numpy(), single), f"chain of {blocks}"
+        assert np.array_equal(sample_tokens(True), tokens_single) and np.array_equal(sample_tokens(False), tokens_single)
+    m.check_errors()
 
 
 @pytest.mark.parametrize("cfg,B,L", [(BIG640, 4, 512), (BIG640, 16, 130), (BIG640, 64, 256), (BIG512, 9, 300),
