@@ -1,7 +1,16 @@
 // In-launch hand-off between the phases of a block chain (block_chain.hip): PFF1 -> convolution -> PFF2 of one or more
 // ByteNet blocks run as ONE persistent launch, each workgroup keeping its (row tile, column tile) through all phases.
 //
-// Why: between two launches a CU sits idle from the exit of its workgroup to the first MFMA of the next one - 3.5-4.5 us
+// MEASURED OUTCOME (round 2, config 2, same-process A/B `tools/opt_ab.py block_chain 0 1 2 3`): bit-identical results,
+// and NOT faster - 15.40 ms per diffusion step with one launch per GEMM, 15.56 / 15.95 / 16.06 with chains of 1 / 2 / 3
+// blocks.  Timing-only builds with parts of the hand-off removed (results invalid) show where it goes: without the
+// consumer's acquire 15.31 against 15.74, without any wait 15.24, with plain instead of write-through stores (and the
+// acquire) 15.60, with plain stores + the producer's agent release 15.87.  A hand-off in one of the forms that are
+// valid for any placement costs as much as the launch boundary it replaces; the forms that would be cheaper rely on
+// the workgroups of a row tile sharing an XCD, which the programming guide rules out.  ED_OPT_BLOCK_CHAIN therefore
+// defaults to 0; the code stays as the measured form of the idea and as a second user of the tile bodies.
+//
+// Why it was tried: between two launches a CU sits idle from the exit of its workgroup to the first MFMA of the next one - 3.5-4.5 us
 // until the next launch's workgroup enters (dispatch, LDS and register allocation; measured with in-kernel clocks,
 // tools/kernel_timeline.py; two streams feeding the CUs without any ordering do not shorten it), ~3 us of prologue
 // until the first operands are in LDS, and the launch ends with its slowest XCD.  A phase change inside a launch costs
@@ -34,11 +43,6 @@ struct ChainCtl {
   unsigned final_total = 0;    // > 0: this is the launch's last phase; the arrival that makes the counter this resets it
 };
 
-// cache-policy bits of the LDS-DMA copies of a chain phase's A operand (experiment: 17 = sc0 sc1)
-#ifndef ED_CHAIN_A_AUX
-#define ED_CHAIN_A_AUX 0
-#endif
-constexpr int CHAIN_A_AUX = ED_CHAIN_A_AUX;
 constexpr unsigned long long CHAIN_SPIN_TICKS = 5000000ull;  // 50 ms of the 100-MHz clock
 
 // Called by ALL threads of the workgroup, after the phase's weight copies were issued and before its first A copy.
@@ -57,9 +61,6 @@ __device__ __forceinline__ void chain_wait(const ChainCtl& cc, int tile_m, int t
         }
       }
     }
-#ifdef ED_CHAIN_DELAY
-    for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(127);  // (diagnostic: ~20 us)
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the polling wave, after its poll matched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the invalidate completes asynchronously)
   }
@@ -72,10 +73,6 @@ __device__ __forceinline__ void chain_signal(const ChainCtl& cc, int tile_m, int
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the signalling lane joins
   __syncthreads();
   if (tid == 0) {
-#ifdef ED_CHAIN_PLAIN_STORES
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     gu32* const c = (gu32*)cc.ctr + tile_m;
     const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cc.final_total && old + 1 == cc.final_total) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

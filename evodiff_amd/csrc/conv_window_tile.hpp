@@ -45,10 +45,9 @@ constexpr int SEQ_ROWS = 256, BK = 64, ROW_B = BK * 2;
 constexpr int WIN_ROWS = 320, WIN_BYTES = WIN_ROWS * ROW_B;
 constexpr int NTAPS = 5;
 
-template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
 constexpr int lds_bytes(int nt) { return 2 * WIN_BYTES + 2 * nt * 64 * ROW_B; }
@@ -124,7 +123,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
 
   auto copy_window_group = [&](int ga_raw, char* win) {  // groups past the window re-copy its last one
     const int ga = ga_raw < win_groups ? ga_raw : win_groups - 1;
-    glds16<CHAIN ? CHAIN_A_AUX : 0>(a_next + (unsigned)ga * grp_bytes + ((ga & 1) ? lane_off1 : lane_off0), win + ga * 1024);
+    glds16(a_next + (unsigned)ga * grp_bytes + ((ga & 1) ? lane_off1 : lane_off0), win + ga * 1024);
   };
   auto copy_weight_group = [&](int jj, char* wst) {
     const int grp = wid * NGB + jj;  // LDS rows 8*grp .. +7 <- channels c0 + {0..3, 8..11}

@@ -43,10 +43,9 @@ namespace gemm_tile {
 
 constexpr int BM = 256, BK = 64, ROW_B = BK * 2;  // 128 bytes of K per tile row per step
 
-template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
 constexpr int lds_bytes(int nt, int wm) { return 2 * (wm * 64 + nt * 64) * ROW_B; }
@@ -151,7 +150,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
     if constexpr (ABLATE == 2) return;
     char* st = lds + (dma_t & 1) * STAGE;
     if (j < 4) {  // A rows wid*32 + 8j .. +8   (group wid*4 + j, parity j & 1)
-      glds16<CHAIN ? CHAIN_A_AUX : 0>(a_dma + (unsigned)j * grp_bytes + ((j & 1) ? lane_off1 : lane_off0), st + (wid * 4 + j) * 1024);
+      glds16(a_dma + (unsigned)j * grp_bytes + ((j & 1) ? lane_off1 : lane_off0), st + (wid * 4 + j) * 1024);
     } else {      // W rows n0 + 8*(wid*NGB + jj) .. +8
       const int jj = j - 4, grp = wid * NGB + jj;  // LDS rows 8*grp .. +7 <- channels c0 + {0..3, 8..11} (see below)
       const int c0 = 32 * (grp >> 2) + 16 * (grp & 1) + 4 * ((grp >> 1) & 1);
@@ -279,8 +278,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
       auto load_group = [&](int grp) {
         const float* rb0 = rbase;
         asm volatile("" : "+s"(rb0));  // addresses formed here, step by step, not hoisted out of the unrolled loop
-        // (typed as a global pointer: scalar base + lane offset in the load instruction itself; as a generic pointer
-        // every piece takes a 64-bit address in VGPRs)
+        // (typed as a global pointer; behind the asm the compiler no longer knows the address space)
         const __attribute__((address_space(1))) float* const rb = (const __attribute__((address_space(1))) float*)rb0;
 #pragma unroll
         for (int v = 0; v < APG; ++v) {

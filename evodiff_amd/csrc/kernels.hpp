@@ -51,9 +51,8 @@ struct PosBit {
 };
 
 // A pointer read from a structure in memory is a generic ("flat") pointer to the compiler; the tile bodies mark the
-// device-memory pointers of a problem as global ones, so that loads and stores through them keep the scalar-base +
-// lane-offset addressing of global_load / global_store (pointers that arrive as kernel arguments already have it; the
-// block chain reads its problems through a laundered pointer and lost it: 40 flat loads and 28 spilled registers).
+// device-memory pointers of a problem as global ones, so that loads and stores through them stay global_load /
+// global_store whether the problem arrives as a kernel argument or (block chain) through a laundered pointer.
 #if defined(__HIPCC__)
 template <typename T>
 __device__ __forceinline__ T* as_global(T* p) {

@@ -267,12 +267,7 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
       if (orow[ip] >= 0 && !(f.dbg & 4)) {
         const lnbf16x8 pk = {(__bf16)y[0].x, (__bf16)y[0].y, (__bf16)y[1].x, (__bf16)y[1].y,
                              (__bf16)y[2].x, (__bf16)y[2].y, (__bf16)y[3].x, (__bf16)y[3].y};
-#ifdef ED_CHAIN_PLAIN_STORES
-        if constexpr (false) {
-        }
-#else
         if constexpr (WT) store16_wt(wt, (unsigned)((orow[ip] * g.N + nb + 32 * jp) * 2), pk);
-#endif
         else *(lnbf16x8*)(as_global(f.out) + orow[ip] * g.N + nb + 32 * jp) = pk;
       }
     }
