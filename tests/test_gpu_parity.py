@@ -834,6 +834,36 @@ def test_autoregressive_sampler_vs_oracle(dev, base, precision, max_len):
             again, uni.t().contiguous().to(dev), n_steps=max_len)
 
 
+def test_in_launch_exchanges_under_uneven_load(dev):
+    """The workgroups of a row tile exchange statistics (fused LayerNorm) or rows (block chain) INSIDE a launch.  An
+    idle chip hides most hand-off mistakes, so here other work runs next to them: a second stream keeps launching
+    matrix products of changing size, which take CUs away at arbitrary moments and delay some workgroups of a row tile
+    against the others.  Every forward must still equal the quiet one bit for bit and no bounded wait may run out."""
+    cfg, B, L = WIDE1280, 64, 256
+    cfg = dict(cfg, n_layers=6)
+    oracle = R.build_model(cfg, None, 78)
+    m = product_model(oracle, cfg, precision="bf16")
+    x = torch.from_numpy(np.random.default_rng(6).integers(0, 31, (B, L))).to(dev)
+    t = torch.zeros(B, dtype=torch.long, device=dev)
+    quiet = {}
+    for blocks in (0, 2):
+        m.set_option("block_chain", blocks)
+        quiet[blocks] = m(x, t).clone()
+    assert torch.equal(quiet[0], quiet[2])
+    side = torch.cuda.Stream()
+    mats = [torch.randn((n, n), device=dev, dtype=torch.bfloat16) for n in (512, 1536, 3072, 4096)]
+    torch.cuda.synchronize()
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for k in range(6):
+                a = mats[(rep + k) % len(mats)]
+                a @ a
+        m.set_option("block_chain", 0 if rep % 2 == 0 else 2)
+        assert torch.equal(m(x, t), quiet[0]), f"rep {rep}"
+    torch.cuda.synchronize()
+    m.check_errors()
+
+
 def test_block_chain_is_bit_identical_to_single_launches(dev):
     """ED_OPT_BLOCK_CHAIN: PFF1 -> convolution -> PFF2 of 1, 2 or 3 consecutive blocks as ONE persistent launch whose
     workgroups hand their rows over inside the launch (chain.hpp).  Same kernels' tile bodies, same arithmetic: logits and
