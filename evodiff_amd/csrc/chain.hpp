@@ -25,8 +25,9 @@
 //             workgroup barrier; ONE lane adds 1 to the row tile's chain counter (agent-scope atomic);
 //   consumer: ONE lane polls that counter (relaxed, agent scope, bounded) until phase_index * tiles_n arrivals are in;
 //             its wave runs the agent acquire (buffer_inv sc1: this CU's L1 holds lines of the same buffers from the
-//             block before) and waits for it; workgroup barrier; only then the first copy of the phase's A operand is
-//             issued.  The weights' first copies are issued BEFORE the wait - they depend on nothing.
+//             block before) and waits for it; workgroup barrier; only then the phase begins.  (The wait is the very
+//             first thing a phase does: behind the first weight copies, which depend on nothing, it would hide ~1 us
+//             more, but a barrier between a phase's address set-up and its unrolled K loop costs 21 spilled registers.)
 // Counters are zero between launches: the arrival that completes the last phase of a launch stores 0 (every wait on the
 // counter has been satisfied by then).  Nothing is assumed about dispatch order or workgroup -> XCD placement; what IS
 // assumed is that all workgroups of the launch are resident at once (grid <= number of CUs, one workgroup per CU by its
@@ -45,7 +46,7 @@ struct ChainCtl {
 
 constexpr unsigned long long CHAIN_SPIN_TICKS = 5000000ull;  // 50 ms of the 100-MHz clock
 
-// Called by ALL threads of the workgroup, after the phase's weight copies were issued and before its first A copy.
+// Called by ALL threads of the workgroup as the first thing of a phase.
 __device__ __forceinline__ void chain_wait(const ChainCtl& cc, int tile_m, int tid) {
   if (cc.wait_target == 0) return;  // (uniform)
   typedef __attribute__((address_space(1))) unsigned int gu32;
