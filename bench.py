@@ -141,12 +141,16 @@ class Job:
         self.dry = args.dry_run
         if self.world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # the collectives run when there is more than one rank - or, to rehearse the RCCL calls on a one-GPU box, when a
+        # launcher set up a one-rank group and EVODIFF_BENCH_FORCE_COLLECTIVE=1 asks for them
+        self.collective = self.world > 1 or ("WORLD_SIZE" in os.environ and
+                                             os.environ.get("EVODIFF_BENCH_FORCE_COLLECTIVE") == "1")
         if self.dry:
             self.dev = torch.device("cpu")
         else:
             torch.cuda.set_device(self.local_rank)
             self.dev = torch.device("cuda", self.local_rank)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             if self.dry:
                 dist.init_process_group("gloo")
@@ -156,14 +160,14 @@ class Job:
     def fence(self):
         if not self.dry:
             torch.cuda.synchronize(self.dev)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.barrier()
             if not self.dry:
                 torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, elapsed):
-        if self.world == 1:
+        if not self.collective:
             return elapsed
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
@@ -171,7 +175,7 @@ class Job:
         return float(t.item())
 
     def close(self):
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.barrier()
             dist.destroy_process_group()
@@ -335,7 +339,7 @@ def main():
         orders = [torch.from_numpy(batch_order(SEED_ORDER, j, L)).to(dev) for j in batches]
         uniforms = [torch.from_numpy(sequence_uniforms(SEED_UNIFORM, j * B, (j + 1) * B, (L,))).to(dev) for j in batches]
         samples = [torch.full((B, L), mask_id, dtype=torch.long, device=dev) for _ in range(total)]
-    gathered = [torch.empty((world * B, L), dtype=torch.long, device=dev) for _ in range(total)] if world > 1 else None
+    gathered = [torch.empty((world * B, L), dtype=torch.long, device=dev) for _ in range(total)] if job.collective else None
 
     def one_step(i):
         if job.dry:
@@ -344,7 +348,7 @@ def main():
             model.d3pm_sample(samples[i], Q, Q_bar, uniforms[i], tokenizer.K)      # all T - 1 reverse steps
         else:
             model.oadm_sample(samples[i], orders[i], uniforms[i], n_draw)
-        if world > 1:
+        if job.collective:
             import torch.distributed as dist
             dist.all_gather_into_tensor(gathered[i], samples[i])   # RCCL over xGMI: the finished sequences
 
@@ -367,7 +371,7 @@ def main():
         stats = model.probe_read()
         model.probe(0)
     # every timed step's sequences over all ranks = global batches warmup*world .. total*world - 1, in order
-    done = torch.cat((gathered if world > 1 else samples)[args.warmup:], dim=0)
+    done = torch.cat((gathered if job.collective else samples)[args.warmup:], dim=0)
     if d3pm:
         assert int(done.min()) >= 0 and int(done.max()) < tokenizer.K - 6, "last D3PM step draws canonical residues"
     else:
