@@ -128,6 +128,7 @@ struct ed_model {
   int chain_blocks = 0;
   int n_cus = 0;      // CUs of the model's device (a chain launch needs all its workgroups resident at once)
   DevBuf chain_ctr;   // one counter per row tile, zero between launches
+  int64_t chain_launches = 0;  // ed_debug_chain_launches
   DevBuf Abuf1, ln_stats, ln_counters;
   long ln_counter_pitch = 0;
   unsigned* ln_err_host = nullptr;  // ED_AERR_WORDS host-visible words the kernels raise (kernels.hpp), checked by the
@@ -590,6 +591,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
   auto flush_chain = [&]() -> int {
     if (n_chain == 0) return ED_OK;
     LAUNCH_TRY(launch_block_chain(chain, n_chain, m->chain_ctr.as<unsigned>(), m->ln_err_dev + ED_AERR_LN_WAIT, s));
+    ++m->chain_launches;
     n_chain = 0;
     return ED_OK;
   };
@@ -1466,6 +1468,8 @@ int ed_model_set_option(ed_model* m, int option, int value) {
   m->drop_graphs();  // the captured launch sequences depend on both options
   return ED_OK;
 }
+
+int64_t ed_debug_chain_launches(const ed_model* m) { return m ? m->chain_launches : -1; }
 
 int ed_model_check_errors(ed_model* m, void* stream, int synchronize) {
   if (!m) return fail(ED_EINVAL, "null model handle");

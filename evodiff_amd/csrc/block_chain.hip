@@ -89,14 +89,16 @@ bool block_chain_supported(const ChainBlock& b, int n_cus) {
   if (g1.ablate || gc.ablate || g2.ablate) return false;
   if (g1.N % 320 || gc.N != g1.N || g2.N != g1.N) return false;
   if (g1.ntaps != 1 || g2.ntaps != 1 || gc.ntaps != 5 || g1.resid || gc.resid || !g2.resid) return false;
-  if (!g1.out_bf16 && g1.out) { /* the raw result is not stored in the fused form */ }
   // a row tile is a whole sequence of exactly 256 positions: the convolution then reads only rows its own row tile's
   // workgroups produced, and the 1x1 projections (one flat sequence of B * 256 rows) tile the same way
   if (gc.L != 256 || gc.B < 1) return false;
   const long rows = (long)gc.B * 256;
   if (g1.B != 1 || g2.B != 1 || g1.L != rows || g2.L != rows) return false;
-  // PFF2 in its unrolled form with the residual streamed inside the K loop
+  // PFF2 in its unrolled form with the residual streamed inside the K loop; write-through offsets are 32-bit
   if (g2.K != 20 * 64 || g2.resid_mul != 1 || g2.out_bf16) return false;
+  if ((long)gc.B * (gc.ln.out_pitch > 0 ? gc.ln.out_pitch : 256) * gc.N * 2 >= (1L << 31) ||
+      (long)g1.B * g1.L * g1.N * 2 >= (1L << 31) || (g1.ln.seq_len > 0 && (g1.L / g1.ln.seq_len + 1) * g1.ln.out_pitch * g1.N * 2 >= (1L << 31)))
+    return false;
   if (gemm_bf16_tile_rows(g1) != 256 || gemm_bf16_tile_rows(gc) != 256 || gemm_bf16_tile_rows(g2) != 256) return false;
   conv_tile::WindowPlan wp;
   if (!conv_tile::plan_256(gc, &wp)) return false;

@@ -159,6 +159,10 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
  * No counterpart in the reference (its errors are Python exceptions raised by the indexing op itself). */
 int ed_model_check_errors(ed_model* m, void* stream, int synchronize);
 
+/* Diagnostic (no counterpart in the reference): the number of block-chain launches (ED_OPT_BLOCK_CHAIN) this model has
+ * issued or captured so far - lets a test tell that the chain really ran where it expects it to.  -1 for a null handle. */
+int64_t ed_debug_chain_launches(const ed_model* m);
+
 /* Execution options (no counterpart in the reference).  They select kernels and what is recomputed, never the
  * function: with ED_PREC_FP32 the results are bit-identical under every setting; with ED_PREC_BF16 different settings
  * select kernels with different (fixed) orders of rounding, and results agree within the bf16 tolerance.

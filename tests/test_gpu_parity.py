@@ -892,10 +892,16 @@ def test_block_chain_is_bit_identical_to_single_launches(dev):
         return sample.cpu().numpy()
 
     tokens_single = sample_tokens(True)
+    from evodiff_amd import _lib
+    chain_launches = lambda: int(_lib.load().ed_debug_chain_launches(m._handle))
+    assert chain_launches() == 0
     for blocks in (1, 2, 3):
         m.set_option("block_chain", blocks)
+        before = chain_launches()
         for _ in range(3):
             assert np.array_equal(m(x.to(dev), t).cpu().numpy(), single), f"chain of {blocks}"
+        # 9 of the 10 blocks qualify (the last has no next block's LayerNorm to apply): ceil(9 / blocks) launches a forward
+        assert chain_launches() - before == 3 * -(-9 // blocks)
         assert np.array_equal(sample_tokens(True), tokens_single) and np.array_equal(sample_tokens(False), tokens_single)
     m.check_errors()
 
