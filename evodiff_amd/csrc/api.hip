@@ -115,6 +115,7 @@ struct ed_model {
   int n_inc = 0;
   int inc_r[MAX_INC + 1] = {0, 0, 0, 0, 0};  // inc_r[k + 1] = r_k; inc_r[0] = 0 (the changed token itself)
   DevBuf Xc[MAX_INC + 1], Cc[MAX_INC];
+  DevBuf A1c;  // LayerNorm 1 of the first NON-incremental layer, kept across steps: only the window its input changed in is redone
   // Autoregressive sampling of a causal model (ed_ar_sample): the convolution inputs of EVERY layer are kept (past rows
   // never change), a step computes one new row per sequence and layer.  Car[k]: [B][conv_pitch][d_hidden].
   std::vector<DevBuf> Car;
@@ -494,6 +495,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
     }
   }
   for (int k = 0; k <= m->n_inc && m->n_inc > 0; ++k) HIP_TRY(need(m->Xc[k], rows * c.d_model * 4));
+  if (m->n_inc > 0) HIP_TRY(need(m->A1c, rows * Cmax * 4));
   for (int k = 0; k < m->n_inc; ++k) {
     const bool fresh = relayout || cbytes > m->Cc[k].bytes;
     HIP_TRY(need(m->Cc[k], cbytes));
@@ -585,6 +587,7 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
   // LayerNorm output is rounded to bf16 right after anyway), which cuts a third of the LayerNorm traffic
   const bool y_bf16 = h;
   bool ln1_done = false;  // the previous block's PFF2 reduction already ran this block's first LayerNorm
+  auto pruned_here = [](const LayerPlan& pl) { return pl.s_in != 1 || pl.s_out != 1; };
   // blocks collected for one chain launch (ED_OPT_BLOCK_CHAIN); flushed when full or when a block does not qualify
   ChainBlock chain[CHAIN_MAX_BLOCKS];
   int n_chain = 0;
@@ -617,12 +620,30 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     } else if (i == n_inc && n_inc > 0) {
       x_src = m->Xc[i].as<float>();
     }
+    // The first layer behind the incremental ones: its input only changed inside the last incremental layer's output
+    // window, so its LayerNorm 1 is kept across steps (A1c) and only that window is redone
+    const bool cached_ln1 = n_inc > 0 && i == n_inc && !pruned_here(pl);        // this block reads A1c
+    const bool next_cached = n_inc > 0 && i + 1 == n_inc;                         // the next block does: its LN1 goes there
+    void* const A1_in = cached_ln1 ? m->A1c.p : A1;     // this block's LayerNorm 1 result, the input of its PFF1
+    void* const A1_next = next_cached ? m->A1c.p : A1;  // where a PFF2 that applies the next block's LayerNorm 1 puts it
+    if (cached_ln1 && !ln1_done) {
+      if ((rc = flush_chain())) return rc;
+      if (variant == STEP_INCR) {
+        const int M_w = 2 * m->inc_r[n_inc] + 1;
+        const PosBit win = PosBit::window(m->order.as<int>(), m->state.as<StepState>(), m->inc_r[n_inc], L - M_w);
+        const LnRowMap window{M_w, L, 0, 1, win, L, 0, win};
+        if ((rc = run_ln(m, x_src, false, A1_in, h, w.ln1_g, w.ln1_b, B * M_w, D, window, act, s))) return rc;
+      } else {
+        if ((rc = run_ln(m, x_src, false, A1_in, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+      }
+      ln1_done = true;
+    }
     // Block chain: a block at every position whose three GEMMs all apply the LayerNorm behind them joins the pending
     // chain launch (not while the probe times single launches or the per-layer activations are collected)
     if (m->chain_blocks > 0 && h && !acts && !m->probing_now && pl.s_in == 1 && pl.s_out == 1 && i + 1 < c.n_layers &&
         m->chain_ctr.p) {
       ChainBlock cb;
-      cb.g1 = GemmProblem{A1, rows_in, 0, (const void*)w.w1_h, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, true, true};
+      cb.g1 = GemmProblem{A1_in, rows_in, 0, (const void*)w.w1_h, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, true, true};
       cb.gc = GemmProblem{cpad, m->conv_pitch, m->conv_row0, (const void*)w.wc_h, w.bc, Y, nullptr, B, L, H, H, c.kernel_size,
                           w.dilation, true, true};
       cb.gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
@@ -630,10 +651,10 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       const LayerW& wn = m->layers[i + 1];
       if (fuse_ln_into(m, cb.g1, 0, w.ln2_g, w.ln2_b, cpad, L, m->conv_pitch, m->conv_row0) &&
           fuse_ln_into(m, cb.gc, 1, w.ln3_g, w.ln3_b, A, 0, 0, 0) &&
-          fuse_ln_into(m, cb.g2, 2, wn.ln1_g, wn.ln1_b, A1, 0, 0, 0) && block_chain_supported(cb, m->n_cus)) {
+          fuse_ln_into(m, cb.g2, 2, wn.ln1_g, wn.ln1_b, A1_next, 0, 0, 0) && block_chain_supported(cb, m->n_cus)) {
         if (!ln1_done) {  // (only ever the first block of a chain: the blocks behind it get their input from PFF2)
           if ((rc = flush_chain())) return rc;
-          if ((rc = run_ln(m, x_src, false, A1, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+          if ((rc = run_ln(m, x_src, false, A1_in, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
         }
         chain[n_chain++] = cb;
         ln1_done = true;
@@ -643,9 +664,9 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     }
     if ((rc = flush_chain())) return rc;
     // the 1x1 projections are row-independent: tile them over all rows as one long sequence
-    if (!ln1_done && (rc = run_ln(m, x_src, false, A1, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
+    if (!ln1_done && (rc = run_ln(m, x_src, false, A1_in, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
     ln1_done = false;
-    GemmProblem g1{A1, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
+    GemmProblem g1{A1_in, rows_in, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, h, y_bf16};
     GemmProblem dq{};
     long y_pitch;  // rows per sequence of the convolution result in Y
     bool ln3_fused = false;
@@ -699,12 +720,12 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     // also stores the new residual stream)
     GemmProblem dq2{};
     const bool has_next = i + 1 < c.n_layers;
-    const bool ln1_fused = has_next && fuse_ln_into(m, g2, 2, m->layers[i + 1].ln1_g, m->layers[i + 1].ln1_b, A1, 0, 0, 0);
+    const bool ln1_fused = has_next && fuse_ln_into(m, g2, 2, m->layers[i + 1].ln1_g, m->layers[i + 1].ln1_b, A1_next, 0, 0, 0);
     if ((rc = run_gemm(m, g2, ED_K_GEMM1X1, s, h && has_next && !ln1_fused ? &dq2 : nullptr))) return rc;
     if (ln1_fused) ln1_done = true;
     if (dq2.ksplit > 1) {
       const LayerW& wn = m->layers[i + 1];
-      if ((rc = run_ln_after(m, dq2, nullptr, false, A1, h, wn.ln1_g, wn.ln1_b, rows_out, D, LnRowMap::plain(rows_out), act, s))) return rc;
+      if ((rc = run_ln_after(m, dq2, nullptr, false, A1_next, h, wn.ln1_g, wn.ln1_b, rows_out, D, LnRowMap::plain(rows_out), act, s))) return rc;
       ln1_done = true;
     }
     if (acts)
