@@ -834,6 +834,39 @@ def test_autoregressive_sampler_vs_oracle(dev, base, precision, max_len):
             again, uni.t().contiguous().to(dev), n_steps=max_len)
 
 
+def test_flagship_geometry_free_running_bf16_trajectory_against_oracle(dev):
+    """The 640M block geometry at BASELINE config 2's batch (d_model = d_hidden = 1280, 64 sequences of 256: one tile per
+    CU, the 20-step PFF2 with the residual inside its K loop, the windowed convolution at every dilation, LayerNorms in
+    the epilogues, incremental leading layers with the cached LayerNorm 1, pruned trailing layers) sampling FREE-RUNNING
+    in bf16 under graph replay - and every draw of three of the sequences checked against the oracle, teacher-forced
+    along the GPU's own trajectory: the state before step s is the final sample with positions order[s:] masked again,
+    the oracle's fp32 softmax row at order[s] must agree with the GPU's draw wherever the uniform is not within
+    DRAW_MARGIN_BF16 of a category boundary."""
+    cfg, B, L, n = WIDE1280, 64, 256, 12
+    oracle = R.build_model(cfg, None, 91)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(8.0)       # peaky softmax rows: the draws are not all near-uniform
+    m = product_model(oracle, cfg, precision="bf16")
+    m.use_graph = True
+    order = np.random.default_rng(7).permutation(L)[:n].astype(np.int32)
+    uni = torch.from_numpy(np.random.default_rng(8).random((n, B), dtype=np.float32))
+    sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+    m.oadm_sample(sample, torch.from_numpy(order), uni.to(dev), R.OADM_DRAW)
+    m.check_errors()
+    final = sample.cpu()
+    assert (final[:, order] < R.OADM_DRAW).all() and int((final == R.MASK_ID).sum()) == B * (L - n)
+    rows = [0, 31, 63]
+    n_safe = 0
+    for s in range(n):
+        state = final[rows].clone()
+        state[:, order[s:]] = R.MASK_ID
+        with torch.no_grad():
+            logits = oracle(state, torch.zeros(len(rows), dtype=torch.long))[:, int(order[s]), :R.OADM_DRAW]
+        idx, margin = R.inverse_cdf(torch.softmax(logits, dim=-1), uni[s, rows])
+        n_safe += _check_draws(final[rows, int(order[s])].numpy(), idx.numpy(), margin.numpy(), DRAW_MARGIN_BF16)
+    assert n_safe > 0.5 * n * len(rows), "test is vacuous: most draws sit on a category boundary"
+
+
 def test_in_launch_exchanges_under_uneven_load(dev):
     """The workgroups of a row tile exchange statistics (fused LayerNorm) or rows (block chain) INSIDE a launch.  An
     idle chip hides most hand-off mistakes, so here other work runs next to them: a second stream keeps launching
