@@ -867,6 +867,23 @@ def test_flagship_geometry_free_running_bf16_trajectory_against_oracle(dev):
     assert n_safe > 0.5 * n * len(rows), "test is vacuous: most draws sit on a category boundary"
 
 
+def test_flagship_geometry_d3pm_forward_against_oracle(dev):
+    """The same geometry with the D3PM time encoding (per-sequence timesteps through the reshape quirk Q1): bf16 logits of
+    the whole batch against the oracle on a few of its sequences - the oracle must see the WHOLE timestep vector, because
+    row r of the flattened batch takes y[r % B] (evodiff/model.py:131-140)."""
+    cfg, B, L = dict(WIDE1280, n_layers=6), 64, 256
+    oracle = R.build_model(cfg, 500, 92)
+    m = product_model(oracle, cfg, timesteps=500, precision="bf16")
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.integers(0, 26, (B, L)))
+    y = torch.from_numpy(rng.integers(0, 500, (B,)))
+    got = m(x.to(dev), y.to(dev)).cpu().numpy()
+    with torch.no_grad():
+        ref = oracle(x, y).numpy()
+    assert rel_err(got, ref) < BF16_TOL
+    m.check_errors()
+
+
 def test_in_launch_exchanges_under_uneven_load(dev):
     """The workgroups of a row tile exchange statistics (fused LayerNorm) or rows (block chain) INSIDE a launch.  An
     idle chip hides most hand-off mistakes, so here other work runs next to them: a second stream keeps launching
