@@ -13,13 +13,13 @@ K_EMBED, K_LNACT, K_GEMM1X1, K_CONV, K_FINAL, K_CONV_OTHER, K_COUNT = 0, 1, 2, 3
 KIND_NAMES = ("embed", "ln_act", "gemm1x1", "conv", "final", "conv_other")
 OPTIONS = {"prune": 0, "min_tuned_tiles": 1, "split_target": 2, "incremental": 3, "fuse_reduce_ln": 4,
            "split_min_iters": 5, "partials_mb": 6, "tile64_max": 7,
-           "tuned_split_min_rows": 8, "fuse_ln": 9, "block_chain": 10}   # ED_OPT_* in include/evodiff_hip.h
+           "tuned_split_min_rows": 8, "fuse_ln": 9}   # ED_OPT_* in include/evodiff_hip.h
 
 # every symbol include/evodiff_hip.h declares
 SYMBOLS = ("ed_abi_version", "ed_last_error", "ed_model_create", "ed_model_destroy", "ed_model_load_tensor",
            "ed_model_commit", "ed_model_num_params", "ed_forward", "ed_forward_collect", "ed_score_nll", "ed_ar_sample", "ed_oadm_sample",
            "ed_d3pm_sample", "ed_model_set_option", "ed_probe_config", "ed_probe_read", "ed_debug_gemm",
-           "ed_debug_ln_act", "ed_debug_set_stamp_buffer", "ed_debug_gemm_splitk_noalloc", "ed_model_check_errors", "ed_debug_chain_launches")
+           "ed_debug_ln_act", "ed_debug_set_stamp_buffer", "ed_debug_gemm_splitk_noalloc", "ed_model_check_errors")
 
 
 class EdConfig(C.Structure):
@@ -69,8 +69,6 @@ def load():
                                                  i32, vp]
     lib.ed_debug_ln_act.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.ed_model_check_errors.argtypes = [vp, vp, i32]
-    lib.ed_debug_chain_launches.argtypes = [vp]
-    lib.ed_debug_chain_launches.restype = C.c_int64
     lib.ed_probe_config.argtypes = [vp, i32]
     lib.ed_debug_set_stamp_buffer.argtypes = [vp, i64]
     lib.ed_model_set_option.argtypes = [vp, i32, i32]

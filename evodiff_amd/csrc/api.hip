@@ -124,12 +124,6 @@ struct ed_model {
   // partial statistics, arrival counters (one array per GEMM of the block: a counter must always see the same number of
   // column tiles), and a host-visible error word the kernels raise when a bounded wait runs out.
   bool fuse_ln = true;
-  // Block chain (ED_OPT_BLOCK_CHAIN, block_chain.hip): PFF1 -> convolution -> PFF2 of up to this many consecutive blocks
-  // run as one persistent launch when their shapes allow (0 = one launch per GEMM).
-  int chain_blocks = 0;
-  int n_cus = 0;      // CUs of the model's device (a chain launch needs all its workgroups resident at once)
-  DevBuf chain_ctr;   // one counter per row tile, zero between launches
-  int64_t chain_launches = 0;  // ed_debug_chain_launches
   DevBuf Abuf1, ln_stats, ln_counters;
   long ln_counter_pitch = 0;
   unsigned* ln_err_host = nullptr;  // ED_AERR_WORDS host-visible words the kernels raise (kernels.hpp), checked by the
@@ -349,6 +343,11 @@ bool fuse_ln_into(ed_model* m, GemmProblem& p, int kind, const float* gamma, con
   if (!use_tuned_gemm(m, p) || !gemm_bf16_ln_supported(p)) return false;
   const long row_tiles = (long)p.B * ((p.L + 127) / 128);
   if (row_tiles > m->ln_counter_pitch) return false;
+  {  // the exchange slab the launch indexes: (row tile, column tile, tile row) at the tile height the launcher picks
+    const long bm = gemm_bf16_tile_rows(p), tn = p.N % 320 == 0 ? p.N / 320 : p.N / 256;
+    const size_t slots = (size_t)p.B * ((p.L + bm - 1) / bm) * bm * tn;
+    if (slots * 8 > m->ln_stats.bytes) return false;
+  }
   p.ln.gamma = gamma;
   p.ln.beta = beta;
   p.ln.out = (bf16_t*)out;
@@ -465,21 +464,18 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
   HIP_TRY(need(m->partials, (size_t)m->partials_mb << 20));
   {
     HIP_TRY(need(m->Abuf1, rows * Cmax * 4));
-    // fused LayerNorm exchange: a row tile is 128 or 256 rows of ONE sequence, a column tile at least 256 channels
-    const size_t tile_rows = (size_t)B * ((L + 127) / 128) * 128 + 256;
+    // fused LayerNorm exchange: a row tile is 128 or 256 rows of ONE sequence (every row of a ragged last tile has a
+    // slot, so a sequence takes ceil(L / 256) * 256 slots per column tile at the larger tile height), a column tile at
+    // least 256 channels; fuse_ln_into checks every problem against this size
+    const size_t tile_rows = (size_t)B * ((L + 255) / 256) * 256 + 256;
     const size_t max_tn = std::max<size_t>(1, Cmax / 256);
     HIP_TRY(need(m->ln_stats, tile_rows * max_tn * 8));
-    const size_t n_ctr = (tile_rows / 128 + 3) & ~(size_t)3;     // counters per GEMM kind, a multiple of 16 bytes
+    const size_t n_ctr = (((size_t)B * ((L + 127) / 128) * 128 + 256) / 128 + 3) & ~(size_t)3;  // counters per GEMM kind (16-byte multiple)
     if (3 * n_ctr * 4 > m->ln_counters.bytes) {
       HIP_TRY(need(m->ln_counters, 3 * n_ctr * 4));
       HIP_TRY(hipMemsetAsync(m->ln_counters.p, 0, m->ln_counters.bytes, s));  // zero once; launches keep them consistent
     }
     m->ln_counter_pitch = (long)(m->ln_counters.bytes / 12);
-    if (n_ctr * 4 > m->chain_ctr.bytes) {
-      HIP_TRY(need(m->chain_ctr, n_ctr * 4));
-      HIP_TRY(hipMemsetAsync(m->chain_ctr.p, 0, m->chain_ctr.bytes, s));  // zero once; every chain launch leaves them zero
-    }
-    if (!m->n_cus) HIP_TRY(hipDeviceGetAttribute(&m->n_cus, hipDeviceAttributeMultiprocessorCount, m->device));
   }
   // incremental leading layers: as many as keep their window problems on the small-tile kernel, none of them pruned
   m->n_inc = 0;
@@ -588,20 +584,9 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
   const bool y_bf16 = h;
   bool ln1_done = false;  // the previous block's PFF2 reduction already ran this block's first LayerNorm
   auto pruned_here = [](const LayerPlan& pl) { return pl.s_in != 1 || pl.s_out != 1; };
-  // blocks collected for one chain launch (ED_OPT_BLOCK_CHAIN); flushed when full or when a block does not qualify
-  ChainBlock chain[CHAIN_MAX_BLOCKS];
-  int n_chain = 0;
-  auto flush_chain = [&]() -> int {
-    if (n_chain == 0) return ED_OK;
-    LAUNCH_TRY(launch_block_chain(chain, n_chain, m->chain_ctr.as<unsigned>(), m->ln_err_dev + ED_AERR_LN_WAIT, s));
-    ++m->chain_launches;
-    n_chain = 0;
-    return ED_OK;
-  };
   for (int i = 0; i < c.n_layers; ++i) {
     int rc;
     if (variant == STEP_INCR && i < n_inc) {
-      if ((rc = flush_chain())) return rc;
       if ((rc = run_incremental_layer(m, i, B, L, prec, s))) return rc;
       continue;
     }
@@ -627,7 +612,6 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     void* const A1_in = cached_ln1 ? m->A1c.p : A1;     // this block's LayerNorm 1 result, the input of its PFF1
     void* const A1_next = next_cached ? m->A1c.p : A1;  // where a PFF2 that applies the next block's LayerNorm 1 puts it
     if (cached_ln1 && !ln1_done) {
-      if ((rc = flush_chain())) return rc;
       if (variant == STEP_INCR) {
         const int M_w = 2 * m->inc_r[n_inc] + 1;
         const PosBit win = PosBit::window(m->order.as<int>(), m->state.as<StepState>(), m->inc_r[n_inc], L - M_w);
@@ -638,31 +622,6 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
       }
       ln1_done = true;
     }
-    // Block chain: a block at every position whose three GEMMs all apply the LayerNorm behind them joins the pending
-    // chain launch (not while the probe times single launches or the per-layer activations are collected)
-    if (m->chain_blocks > 0 && h && !acts && !m->probing_now && pl.s_in == 1 && pl.s_out == 1 && i + 1 < c.n_layers &&
-        m->chain_ctr.p) {
-      ChainBlock cb;
-      cb.g1 = GemmProblem{A1_in, rows_in, 0, (const void*)w.w1_h, w.b1, Y, nullptr, 1, rows_in, H, D, 1, 1, true, true};
-      cb.gc = GemmProblem{cpad, m->conv_pitch, m->conv_row0, (const void*)w.wc_h, w.bc, Y, nullptr, B, L, H, H, c.kernel_size,
-                          w.dilation, true, true};
-      cb.gc.tap_center = c.causal ? c.kernel_size - 1 : -1;
-      cb.g2 = GemmProblem{A, rows_out, 0, (const void*)w.w2_h, w.b2, x_dst, x_src, 1, rows_out, D, H, 1, 1, true, false};
-      const LayerW& wn = m->layers[i + 1];
-      if (fuse_ln_into(m, cb.g1, 0, w.ln2_g, w.ln2_b, cpad, L, m->conv_pitch, m->conv_row0) &&
-          fuse_ln_into(m, cb.gc, 1, w.ln3_g, w.ln3_b, A, 0, 0, 0) &&
-          fuse_ln_into(m, cb.g2, 2, wn.ln1_g, wn.ln1_b, A1_next, 0, 0, 0) && block_chain_supported(cb, m->n_cus)) {
-        if (!ln1_done) {  // (only ever the first block of a chain: the blocks behind it get their input from PFF2)
-          if ((rc = flush_chain())) return rc;
-          if ((rc = run_ln(m, x_src, false, A1_in, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
-        }
-        chain[n_chain++] = cb;
-        ln1_done = true;
-        if (n_chain == std::min(m->chain_blocks, CHAIN_MAX_BLOCKS) && (rc = flush_chain())) return rc;
-        continue;
-      }
-    }
-    if ((rc = flush_chain())) return rc;
     // the 1x1 projections are row-independent: tile them over all rows as one long sequence
     if (!ln1_done && (rc = run_ln(m, x_src, false, A1_in, h, w.ln1_g, w.ln1_b, rows_in, D, LnRowMap::plain(rows_in), act, s))) return rc;
     ln1_done = false;
@@ -730,10 +689,6 @@ int run_blocks(ed_model* m, int B, int L, int prec, float* acts, bool pruned, in
     }
     if (acts)
       HIP_TRY(hipMemcpyAsync(acts + (size_t)(i + 1) * rows_out * D, Xc, (size_t)rows_out * D * 4, hipMemcpyDeviceToDevice, s));
-  }
-  {
-    int rc;
-    if ((rc = flush_chain())) return rc;
   }
   if (x_out) *x_out = Xc;
   return ED_OK;
@@ -1308,14 +1263,22 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
     static unsigned* dbg_err_host = nullptr;
     static unsigned* dbg_err_dev = nullptr;
     if (!gemm_bf16_ln_supported(p)) return fail(ED_EINVAL, "kernel 400+: shape outside the fused-LayerNorm contract");
-    const size_t rows = (size_t)B * ((L + 127) / 128) * 128 + 256;
+    const size_t rows = (size_t)B * ((L + 255) / 256) * 256 + 256;   // every row of a ragged 256-row tile has a slot
+    const size_t dbg_tn = (size_t)(N % 320 == 0 ? N / 320 : N / 256);
+    if (dbg_tn > 8) return fail(ED_EINVAL, "kernel 400+: at most 8 column tiles per row tile");
     HIP_TRY(dbg_ln_out.ensure(rows * N * 2));
     HIP_TRY(dbg_ln_stats.ensure(3 * rows * 8 * 8));
     const int kind = ntaps > 1 ? 1 : resid_dev ? 2 : 0;
-    if (dbg_ln_ctr.bytes < 3 * (rows / 128) * 4) {  // one set of counters (and statistics) per kind of GEMM
+    // one set of counters (and statistics) per kind of GEMM.  A counter must always see the same number of column
+    // tiles and the sets' offsets depend on the shape: any change of geometry starts from zeroed counters again.
+    static size_t dbg_rows = 0, dbg_last_tn = 0;
+    if (dbg_ln_ctr.bytes < 3 * (rows / 128) * 4 || rows != dbg_rows || dbg_tn != dbg_last_tn) {
+      HIP_TRY(hipStreamSynchronize(s));
       HIP_TRY(dbg_ln_ctr.ensure(3 * (rows / 128) * 4));
       HIP_TRY(hipMemsetAsync(dbg_ln_ctr.p, 0, dbg_ln_ctr.bytes, s));
       HIP_TRY(hipStreamSynchronize(s));
+      dbg_rows = rows;
+      dbg_last_tn = dbg_tn;
     }
     if (dbg_ln_vec.bytes < (size_t)N * 8) {
       HIP_TRY(dbg_ln_vec.ensure((size_t)N * 8));
@@ -1474,10 +1437,6 @@ int ed_model_set_option(ed_model* m, int option, int value) {
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_LN takes 0 or 1");
       m->fuse_ln = value != 0;
       break;
-    case ED_OPT_BLOCK_CHAIN:
-      if (value < 0 || value > CHAIN_MAX_BLOCKS) return fail(ED_EINVAL, "ED_OPT_BLOCK_CHAIN must be in [0, %d]", CHAIN_MAX_BLOCKS);
-      m->chain_blocks = value;
-      break;
     case ED_OPT_SPLIT_MIN_ITERS:
       if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");
       m->split_min_iters = value;
@@ -1489,8 +1448,6 @@ int ed_model_set_option(ed_model* m, int option, int value) {
   m->drop_graphs();  // the captured launch sequences depend on both options
   return ED_OK;
 }
-
-int64_t ed_debug_chain_launches(const ed_model* m) { return m ? m->chain_launches : -1; }
 
 int ed_model_check_errors(ed_model* m, void* stream, int synchronize) {
   if (!m) return fail(ED_EINVAL, "null model handle");

@@ -15,7 +15,7 @@ template <int NT, bool OUT_BF16, bool STAMP = false, int WM = 4, bool LNF = fals
 __global__ __launch_bounds__(WM * 128) void conv_window_kernel(GemmProblem g, int tiles_n, int tiles_total,
                                                                WindowPlan wp) {
   __shared__ __attribute__((aligned(1024))) char lds[conv_tile::lds_bytes(NT)];
-  conv_tile::tile<NT, OUT_BF16, STAMP, WM, LNF, false>(g, tiles_n, tiles_total, wp, lds, (int)blockIdx.x, ChainCtl{});
+  conv_tile::tile<NT, OUT_BF16, STAMP, WM, LNF>(g, tiles_n, tiles_total, wp, lds, (int)blockIdx.x);
 }
 
 }  // namespace
@@ -54,8 +54,6 @@ static int window_wm(const GemmProblem& p, WindowPlan* wp) {
   if (gemm_bf16_tile_rows(p) == 128 && window_plan(p, 2, wp)) return 2;
   return window_plan(p, 4, wp) ? 4 : 0;
 }
-
-bool conv_tile::plan_256(const GemmProblem& p, WindowPlan* wp) { return window_wm(p, wp) == 4; }
 
 bool conv_window_supported(const GemmProblem& p) {
   WindowPlan wp;

@@ -1,5 +1,4 @@
-// Tile body of the windowed convolution (conv_window.hip wraps it in a kernel; block_chain.hip runs it as a phase of a
-// persistent launch).
+// Tile body of the windowed convolution (conv_window.hip wraps it in a kernel).
 //
 // Dilated k=5 convolution of the ByteNet block with the activation window kept in LDS (gfx950, bf16).
 //
@@ -29,7 +28,6 @@
 #pragma once
 #include "kernels.hpp"
 #include "ln_epilogue.hpp"
-#include "chain.hpp"
 
 #include <type_traits>
 
@@ -58,13 +56,10 @@ constexpr int lds_bytes(int nt) { return 2 * WIN_BYTES + 2 * nt * 64 * ROW_B; }
 // leave half of the CUs without a 256-row tile.
 // LNF: the LayerNorm + GELU behind the convolution (g.ln) is applied in the epilogue (ln_epilogue.hpp) and only the
 // normalised rows are stored.
-// CHAIN: the tile is one phase of a block chain (chain.hpp; a row tile must be a whole sequence): the window copies wait
-// for the producers of the row tile, the normalised rows leave write-through, the tile's completion is signalled.
 // `lds`: lds_bytes(NT) bytes, 1024-byte aligned; bid_x: the workgroup's index in the launch grid.
-template <int NT, bool OUT_BF16, bool STAMP = false, int WM = 4, bool LNF = false, bool CHAIN = false>
+template <int NT, bool OUT_BF16, bool STAMP = false, int WM = 4, bool LNF = false>
 __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tiles_total, const WindowPlan& wp, char* lds,
-                                     int bid_x, const ChainCtl& cc) {
-  static_assert(!CHAIN || (LNF && !STAMP), "chain phases: the fused-LayerNorm form");
+                                     int bid_x) {
   constexpr int BM = WM * 64;      // tile rows
   constexpr int NW = 2 * WM;       // waves
   constexpr int BN = NT * 64;
@@ -77,16 +72,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   static_assert(NGB + 3 < NGRP, "copy slots of a step");
   char* const lds_w = lds + 2 * WIN_BYTES;
 
-  // Chain phase: first of all the wait for the producers of this row tile's window (see gemm_bf16_tile.hpp)
-  if constexpr (CHAIN) {
-    const int q = tiles_total >> 3, r = tiles_total & 7, x = bid_x & 7;
-    const int tile0 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid_x >> 3);
-    chain_wait(cc, tile0 / tiles_n, (int)threadIdx.x);
-  }
-  int tid_raw = threadIdx.x;
-  if constexpr (CHAIN) asm volatile("" : "+v"(tid_raw));  // each phase of a chain forms its lane indices afresh: shared
-                                                          // with the other phases they would stay live across every K loop
-  const int tid = tid_raw, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
   unsigned long long r_entry = 0;
@@ -261,10 +247,8 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
     if constexpr (STAMP) {
       if (tid == 0) g.stamps[8 * tile + 6] = (long long)__builtin_amdgcn_s_memrealtime();  // statistics published
     }
-    ln_finish<NT, WM, false, CHAIN>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e,
-                                    g.L - l0e < BM ? g.L - l0e : BM, n0, tid,
-                                    STAMP ? g.stamps + 8 * tile : nullptr);
-    if constexpr (CHAIN) chain_signal(cc, tile_m, tid);
+    ln_finish<NT, WM, false>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e,
+                             g.L - l0e < BM ? g.L - l0e : BM, n0, tid, STAMP ? g.stamps + 8 * tile : nullptr);
     if constexpr (STAMP) {
       __builtin_amdgcn_s_waitcnt(0);
       if (tid == 0) g.stamps[8 * tile + 7] = (long long)__builtin_amdgcn_s_memrealtime();

@@ -13,8 +13,8 @@ template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT =
           bool LNF = false>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(GemmProblem g, int tiles_n, int tiles_total) {
   __shared__ __attribute__((aligned(1024))) char lds[gemm_tile::lds_bytes(NT, WM)];
-  gemm_tile::tile<NT, CONV, OUT_BF16, RESID, ABLATE, RT, WM, SPLIT, LNF, false>(g, tiles_n, tiles_total, lds, (int)blockIdx.x,
-                                                                               (int)blockIdx.y, ChainCtl{});
+  gemm_tile::tile<NT, CONV, OUT_BF16, RESID, ABLATE, RT, WM, SPLIT, LNF>(g, tiles_n, tiles_total, lds, (int)blockIdx.x,
+                                                                        (int)blockIdx.y);
 }
 
 template <int NT, bool CONV, int WM>

@@ -1,5 +1,4 @@
-// Tile body of the tuned bf16 implicit-GEMM kernel (gemm_bf16.hip wraps it in a kernel; block_chain.hip runs it as a
-// phase of a persistent launch).
+// Tile body of the tuned bf16 implicit-GEMM kernel (gemm_bf16.hip wraps it in a kernel).
 //
 // Tuned bf16 implicit-GEMM kernel for the ByteNet block on gfx950 (MI355X).
 //
@@ -32,7 +31,6 @@
 #pragma once
 #include "kernels.hpp"
 #include "ln_epilogue.hpp"
-#include "chain.hpp"
 
 namespace ed {
 
@@ -61,14 +59,10 @@ constexpr int lds_bytes(int nt, int wm) { return 2 * (wm * 64 + nt * 64) * ROW_B
 // or the LayerNorm behind the GEMM).  For problems with too few tiles to fill the chip.
 // LNF: the LayerNorm + GELU behind this GEMM (g.ln) is applied in the epilogue (ln_epilogue.hpp); the raw result is
 // stored only in the residual form (PFF2: it is the residual stream).
-// CHAIN: the tile is one phase of a block chain (chain.hpp): the first A copies wait for the producers of the row tile,
-// the normalised rows leave write-through and the tile's completion is signalled.  `lds`: 2 * (WM*64 + NT*64) * 128 bytes,
-// 1024-byte aligned; bid_x / bid_y: the workgroup's index in the launch grid.
+// `lds`: 2 * (WM*64 + NT*64) * 128 bytes, 1024-byte aligned; bid_x / bid_y: the workgroup's index in the launch grid.
 template <int NT, bool CONV, bool OUT_BF16, bool RESID, int ABLATE = 0, int RT = 0, int WM = 4, bool SPLIT = false,
-          bool LNF = false, bool CHAIN = false>
-__device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tiles_total, char* lds, int bid_x, int bid_y,
-                                     const ChainCtl& cc) {
-  static_assert(!CHAIN || (LNF && !CONV && ABLATE == 0), "chain phases: fused-LayerNorm 1x1 forms");
+          bool LNF = false>
+__device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tiles_total, char* lds, int bid_x, int bid_y) {
   static_assert(!SPLIT || (!OUT_BF16 && !RESID && RT == 0 && ABLATE == 0), "split form: raw fp32 partial sums only");
   static_assert(!LNF || (!SPLIT && (ABLATE == 0 || ABLATE == 3)), "fused LayerNorm: whole sums only");
   constexpr int BM = WM * 64;       // (shadows the file-scope 256)
@@ -81,18 +75,7 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   constexpr int RING = 4;           // weight fragments in flight
   static_assert(NGRP % RING == 0 && N_DMA < NGRP, "step schedule");
 
-  // Chain phase: first of all the wait for the producers of this row tile's A rows.  (Placed behind the first weight
-  // copies - which depend on nothing - it would hide ~1 us more, but any barrier between the address set-up and the K
-  // loop costs the register allocator 21 more spilled registers inside the unrolled loop.)
-  if constexpr (CHAIN) {
-    const int q = tiles_total >> 3, r = tiles_total & 7, x = bid_x & 7;
-    const int tile0 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid_x >> 3);
-    chain_wait(cc, tile0 / tiles_n, (int)threadIdx.x);
-  }
-  int tid_raw = threadIdx.x;
-  if constexpr (CHAIN) asm volatile("" : "+v"(tid_raw));  // each phase of a chain forms its lane indices afresh: shared
-                                                          // with the other phases they would stay live across every K loop
-  const int tid = tid_raw, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
   unsigned long long sc0 = 0, sc1 = 0, sr0 = 0, sr_loop0 = 0;
@@ -345,9 +328,8 @@ __device__ __forceinline__ void tile(const GemmProblem& g, int tiles_n, int tile
   }
   }
   if constexpr (LNF)
-    ln_finish<NT, WM, RESID, CHAIN>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e,
-                                    g.L - l0e < BM ? g.L - l0e : BM, n0, tid);
-  if constexpr (CHAIN) chain_signal(cc, tile_m, tid);
+    ln_finish<NT, WM, RESID>(g, acc, lds, ln_target, tile_m, tiles_n, (long)b * g.L + l0e,
+                             g.L - l0e < BM ? g.L - l0e : BM, n0, tid);
   if constexpr (ABLATE == 3) {  // diagnostic build (eight values per tile): {prologue, K loop, epilogue incl. store
     // drain} cycles, total ticks, then the absolute 100-MHz times of entry, loop start, loop end and exit
     __builtin_amdgcn_s_waitcnt(0);

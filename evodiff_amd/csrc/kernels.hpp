@@ -52,7 +52,7 @@ struct PosBit {
 
 // A pointer read from a structure in memory is a generic ("flat") pointer to the compiler; the tile bodies mark the
 // device-memory pointers of a problem as global ones, so that loads and stores through them stay global_load /
-// global_store whether the problem arrives as a kernel argument or (block chain) through a laundered pointer.
+// global_store however the problem reaches them.
 #if defined(__HIPCC__)
 template <typename T>
 __device__ __forceinline__ T* as_global(T* p) {
@@ -146,23 +146,9 @@ struct WindowPlan {
   int na;          // window groups each wave copies per step (1 .. 3)
   int center;      // tap t reads position l + (t - center) * dilation (2 = 'same' padding, 4 = causal)
 };
-// Window geometry of a problem on 256-row tiles (conv_window.hip); false when the windowed form does not apply.
-bool plan_256(const GemmProblem& p, WindowPlan* wp);
 }  // namespace conv_tile
 bool conv_window_supported(const GemmProblem& p);
 
-// Block chain (block_chain.hip, chain.hpp): PFF1 -> convolution -> PFF2 of up to CHAIN_MAX_BLOCKS ByteNet blocks as ONE
-// persistent launch; every GEMM applies the LayerNorm behind it (GemmProblem::ln set, as for the single launches).
-constexpr int CHAIN_MAX_BLOCKS = 3;  // (the kernel's argument block is limited to 4 KiB)
-struct ChainBlock {
-  GemmProblem g1, gc, g2;
-  conv_tile::WindowPlan wp;  // filled in by launch_block_chain
-};
-// True when the three problems of a block can run as chain phases: 640M-style geometry (all three N = K = 1280-like,
-// 320-column tiles), every row tile a whole 256-position sequence, one tile per CU at most.
-bool block_chain_supported(const ChainBlock& b, int n_cus);
-// `ctr`: one zero-initialised counter per row tile (zero again when the launch ends); `error`: host-visible word.
-hipError_t launch_block_chain(ChainBlock* blocks, int n_blocks, unsigned* ctr, unsigned* error, hipStream_t stream);
 hipError_t launch_conv_window(const GemmProblem& p, hipStream_t stream);
 
 // tokens (B*L) int64 -> X fp32 [B*L][D]:  up_b + up_w @ (emb[tok] + pe[t])   (model.py:131-140)

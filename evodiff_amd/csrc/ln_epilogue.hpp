@@ -27,7 +27,6 @@
 // statistics it has - wrong results with a reported error instead of a hung GPU.
 #pragma once
 #include "kernels.hpp"
-#include "chain.hpp"
 
 namespace ed {
 
@@ -153,8 +152,7 @@ __device__ __forceinline__ unsigned ln_publish(const GemmProblem& g, Acc& acc, c
 // rows AFTER the wait and the statistics loads: issued in front of them (as a separate store loop between the halves)
 // the 40 16-byte stores of a lane sit in front of the poll's and the statistics' loads in the wave's memory queue,
 // and the epilogue waits for their drain twice.
-// WT: the normalised rows leave as write-through stores (block chain: they are handed to other workgroups of the launch).
-template <int NT, int WM, bool RAW = false, bool WT = false, typename Acc>
+template <int NT, int WM, bool RAW = false, typename Acc>
 __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* lds, unsigned target, int tile_m,
                                           int tiles_n, long row_base, int rows_valid, int n0, int tid_in,
                                           long long* stamp = nullptr) {  // stamp: diagnostic builds, two 100-MHz times
@@ -241,7 +239,6 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
     orow[ip] = r < rows_valid ? R : -1;
   }
   float* const raw = RAW ? as_global((float*)g.out) + (row_base + wr * 64 + fr) * g.N + nb : nullptr;
-  const WtBuffer wt = wt_buffer(WT ? (void*)f.out : nullptr);  // (offsets below 2^32 bytes: the chain's launcher checks)
   const float* const gb = (const float*)(lds + BM * 64 + BM * 8) + wc * (BN / 2) + 8 * fq;  // staged by ln_publish
 #pragma unroll
   for (int jp = 0; jp < NT; ++jp) {
@@ -267,8 +264,7 @@ __device__ __forceinline__ void ln_finish(const GemmProblem& g, Acc& acc, char* 
       if (orow[ip] >= 0 && !(f.dbg & 4)) {
         const lnbf16x8 pk = {(__bf16)y[0].x, (__bf16)y[0].y, (__bf16)y[1].x, (__bf16)y[1].y,
                              (__bf16)y[2].x, (__bf16)y[2].y, (__bf16)y[3].x, (__bf16)y[3].y};
-        if constexpr (WT) store16_wt(wt, (unsigned)((orow[ip] * g.N + nb + 32 * jp) * 2), pk);
-        else *(lnbf16x8*)(as_global(f.out) + orow[ip] * g.N + nb + 32 * jp) = pk;
+        *(lnbf16x8*)(as_global(f.out) + orow[ip] * g.N + nb + 32 * jp) = pk;
       }
     }
   }

@@ -159,10 +159,6 @@ int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const 
  * No counterpart in the reference (its errors are Python exceptions raised by the indexing op itself). */
 int ed_model_check_errors(ed_model* m, void* stream, int synchronize);
 
-/* Diagnostic (no counterpart in the reference): the number of block-chain launches (ED_OPT_BLOCK_CHAIN) this model has
- * issued or captured so far - lets a test tell that the chain really ran where it expects it to.  -1 for a null handle. */
-int64_t ed_debug_chain_launches(const ed_model* m);
-
 /* Execution options (no counterpart in the reference).  They select kernels and what is recomputed, never the
  * function: with ED_PREC_FP32 the results are bit-identical under every setting; with ED_PREC_BF16 different settings
  * select kernels with different (fixed) orders of rounding, and results agree within the bf16 tolerance.
@@ -192,14 +188,11 @@ int64_t ed_debug_chain_launches(const ed_model* m);
  *     per-row partial statistics inside the launch - instead of a separate LayerNorm launch; the statistics are then
  *     taken on the fp32 sums rather than on their bf16 roundings.  0 = separate launches.  If a workgroup ever gives up
  *     waiting for its partners (bounded wait), the NEXT call on the model returns ED_EHIP.
- *   ED_OPT_BLOCK_CHAIN (default 0; 0 .. 3): with ED_OPT_FUSE_LN, PFF1 -> convolution -> PFF2 of up to this many
- *     consecutive blocks run as ONE persistent launch (every workgroup keeps its tile through all phases and hands its
- *     rows to the next phase inside the launch) where the geometry allows: 320-column tiles with d_hidden = d_model,
- *     sequences of exactly 256 positions, at most one tile per CU.  Same arithmetic, bit-identical results.  0 = one
- *     launch per GEMM. */
+ *   (Option 10, the round-2 block chain, was measured slower than one launch per GEMM and is gone; the number stays
+ *   unused.) */
 enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1, ED_OPT_SPLIT_TARGET = 2, ED_OPT_INCREMENTAL = 3,
        ED_OPT_FUSE_REDUCE_LN = 4, ED_OPT_SPLIT_MIN_ITERS = 5, ED_OPT_PARTIALS_MB = 6, ED_OPT_TILE64_MAX = 7,
-       ED_OPT_TUNED_SPLIT_MIN_ROWS = 8, ED_OPT_FUSE_LN = 9, ED_OPT_BLOCK_CHAIN = 10 };
+       ED_OPT_TUNED_SPLIT_MIN_ROWS = 8, ED_OPT_FUSE_LN = 9 };
 int ed_model_set_option(ed_model* m, int option, int value);
 
 /* Measurement hooks (no counterpart in the reference).  With a probe interval n > 0, every n-th

@@ -885,21 +885,17 @@ def test_flagship_geometry_d3pm_forward_against_oracle(dev):
 
 
 def test_in_launch_exchanges_under_uneven_load(dev):
-    """The workgroups of a row tile exchange statistics (fused LayerNorm) or rows (block chain) INSIDE a launch.  An
-    idle chip hides most hand-off mistakes, so here other work runs next to them: a second stream keeps launching
-    matrix products of changing size, which take CUs away at arbitrary moments and delay some workgroups of a row tile
-    against the others.  Every forward must still equal the quiet one bit for bit and no bounded wait may run out."""
+    """The workgroups of a row tile exchange statistics (fused LayerNorm) INSIDE a launch.  An idle chip hides most
+    hand-off mistakes, so here other work runs next to them: a second stream keeps launching matrix products of
+    changing size, which take CUs away at arbitrary moments and delay some workgroups of a row tile against the others.
+    Every forward must still equal the quiet one bit for bit and no bounded wait may run out."""
     cfg, B, L = WIDE1280, 64, 256
     cfg = dict(cfg, n_layers=6)
     oracle = R.build_model(cfg, None, 78)
     m = product_model(oracle, cfg, precision="bf16")
     x = torch.from_numpy(np.random.default_rng(6).integers(0, 31, (B, L))).to(dev)
     t = torch.zeros(B, dtype=torch.long, device=dev)
-    quiet = {}
-    for blocks in (0, 2):
-        m.set_option("block_chain", blocks)
-        quiet[blocks] = m(x, t).clone()
-    assert torch.equal(quiet[0], quiet[2])
+    quiet = m(x, t).clone()
     side = torch.cuda.Stream()
     mats = [torch.randn((n, n), device=dev, dtype=torch.bfloat16) for n in (512, 1536, 3072, 4096)]
     torch.cuda.synchronize()
@@ -908,56 +904,16 @@ def test_in_launch_exchanges_under_uneven_load(dev):
             for k in range(6):
                 a = mats[(rep + k) % len(mats)]
                 a @ a
-        m.set_option("block_chain", 0 if rep % 2 == 0 else 2)
-        assert torch.equal(m(x, t), quiet[0]), f"rep {rep}"
+        assert torch.equal(m(x, t), quiet), f"rep {rep}"
     torch.cuda.synchronize()
     m.check_errors()
 
 
-def test_block_chain_is_bit_identical_to_single_launches(dev):
-    """ED_OPT_BLOCK_CHAIN: PFF1 -> convolution -> PFF2 of 1, 2 or 3 consecutive blocks as ONE persistent launch whose
-    workgroups hand their rows over inside the launch (chain.hpp).  Same kernels' tile bodies, same arithmetic: logits and
-    sampled tokens must equal the one-launch-per-GEMM path BIT FOR BIT, every time (a stale or early read of a
-    handed-over row would show as a difference), eager and under graph replay; and both stay within the bf16 tolerance
-    of the oracle.  Geometry: the 640M block (d_model = d_hidden = 1280), 64 sequences of 256 positions = one tile per
-    CU, all eight dilations (windowed and whole-sequence forms of the convolution)."""
-    cfg, B, L = WIDE1280, 64, 256
-    oracle = R.build_model(cfg, None, 77)
-    m = product_model(oracle, cfg, precision="bf16")
-    x = torch.from_numpy(np.random.default_rng(5).integers(0, 31, (B, L)))
-    t = torch.zeros(B, dtype=torch.long, device=dev)
-    m.set_option("block_chain", 0)
-    single = m(x.to(dev), t).cpu().numpy()
-    with torch.no_grad():
-        ref = oracle(x[:4], torch.zeros(4, dtype=torch.long)).numpy()
-    assert rel_err(single[:4], ref) < BF16_TOL
-    n = 12
-    order = torch.from_numpy(np.random.default_rng(L).permutation(L)[:n].astype(np.int32))
-    uni = torch.from_numpy(np.random.default_rng(1).random((n, B), dtype=np.float32)).to(dev)
-
-    def sample_tokens(use_graph):
-        m.use_graph = use_graph
-        sample = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
-        m.oadm_sample(sample, order, uni, R.OADM_DRAW)
-        return sample.cpu().numpy()
-
-    tokens_single = sample_tokens(True)
-    from evodiff_amd import _lib
-    chain_launches = lambda: int(_lib.load().ed_debug_chain_launches(m._handle))
-    assert chain_launches() == 0
-    for blocks in (1, 2, 3):
-        m.set_option("block_chain", blocks)
-        before = chain_launches()
-        for _ in range(3):
-            assert np.array_equal(m(x.to(dev), t).cpu().numpy(), single), f"chain of {blocks}"
-        # 9 of the 10 blocks qualify (the last has no next block's LayerNorm to apply): ceil(9 / blocks) launches a forward
-        assert chain_launches() - before == 3 * -(-9 // blocks)
-        assert np.array_equal(sample_tokens(True), tokens_single) and np.array_equal(sample_tokens(False), tokens_single)
-    m.check_errors()
-
-
 @pytest.mark.parametrize("cfg,B,L", [(BIG640, 4, 512), (BIG640, 16, 130), (BIG640, 64, 256), (BIG512, 9, 300),
-                                     (BIG512, 3, 256), (BIG640, 1, 1024), (BIG640, 5, 77)])
+                                     (BIG512, 3, 256), (BIG640, 1, 1024), (BIG640, 5, 77),
+                                     # 256-row tiles with a ragged last tile per sequence and d_hidden == d_model: the
+                                     # largest statistics slab per token (it used to be sized for 128-row tiles)
+                                     (BIG640, 40, 300), (TINY_WIDE, 200, 100)])
 def test_layernorm_in_gemm_epilogue_matches_separate_launches(dev, cfg, B, L):
     """ED_OPT_FUSE_LN: on the tuned kernels every GEMM of a block applies the LayerNorm + GELU behind it in its own
     epilogue (the column tiles of a row tile exchange per-row statistics inside the launch).  Against separate
