@@ -51,6 +51,36 @@ PEAK_FP32_TFLOPS = 157.3
 SUSTAINED_BF16_TFLOPS = 1953.0
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E
 SEED_ORDER, SEED_UNIFORM, SEED_START = 1000, 2000, 3000
+# The synthetic weights are the reference constructor's default init under seed 0 with the decoder's weight scaled by
+# this factor: default-init logits are nearly flat, so every draw would sit within bf16 noise of a category boundary and
+# a check of the sampled tokens against the oracle would be vacuous.  The decoder runs on one row per sequence and step
+# (fp32, outside every GEMM): the factor changes which tokens are drawn, not the work.
+DECODER_SCALE = 8.0
+
+
+def sharpen_decoder(model, scale):
+    with torch.no_grad():
+        model.decoder.conv.weight.mul_(float(scale))
+
+
+def oracle_spot_check(model, cfg_name, final, order, uniforms, precision, timeout_rows=3, n_steps_checked=12):
+    """After the timed region: the sequences the LAST timed step sampled, checked against the CPU oracle draw by draw
+    (oracle/spot_check.py: three rows x a dozen steps spread over the loop, the oracle teacher-forced along the GPU's own
+    trajectory).  The oracle is the checker here, never the thing measured."""
+    from oracle import bytenet_ref as R
+    from oracle.spot_check import oadm_spot_check, spread_steps
+    t0 = time.perf_counter()
+    oracle = R.build_model(R.MODEL_CONFIGS[cfg_name], None, None)
+    oracle.load_state_dict(model.state_dict())
+    B, L = final.shape
+    rows = sorted({0, B // 2, B - 1})[:timeout_rows]
+    tol = 5e-2 if precision == "bf16" else 1e-4          # tests/test_gpu_parity.py: DRAW_MARGIN_BF16 / _FP32
+    steps = spread_steps(len(order), n_steps_checked)
+    res = oadm_spot_check(oracle, final, order.cpu().numpy(), uniforms, rows, steps, tol)
+    res.update({"rows": rows, "steps": steps, "margin_tol": tol, "seconds": round(time.perf_counter() - t0, 1),
+                "what": "oracle teacher-forced along the sampled trajectory of the last timed batch; a draw is compared "
+                        "when its uniform is further than margin_tol (probability mass) from a category boundary"})
+    return res
 
 
 def _time_oadm_oracle(R, model, L, seconds_budget, min_steps, max_steps):
@@ -141,6 +171,12 @@ class Job:
         self.dry = args.dry_run
         if self.world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not self.dry:
+            # fail loudly and early, on every rank, before any collective can hang on a missing peer
+            have = torch.cuda.device_count()
+            if have < self.local_rank + 1:
+                raise SystemExit(f"rank {self.rank}: LOCAL_RANK={self.local_rank} but this process sees {have} GPU(s); "
+                                 f"a {self.world}-rank job needs one GPU per rank on this node")
         # the collectives run when there is more than one rank - or, to rehearse the RCCL calls on a one-GPU box, when a
         # launcher set up a one-rank group and EVODIFF_BENCH_FORCE_COLLECTIVE=1 asks for them
         self.collective = self.world > 1 or ("WORLD_SIZE" in os.environ and
@@ -156,6 +192,16 @@ class Job:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)
+            if dist.get_world_size() != self.world or dist.get_rank() != self.rank:
+                raise SystemExit(f"process group has {dist.get_world_size()} ranks (this is rank {dist.get_rank()}) but the "
+                                 f"environment says WORLD_SIZE={self.world} RANK={self.rank}")
+
+    def group_size(self):
+        """Ranks that really take part: the process group's size when there is one."""
+        if self.collective:
+            import torch.distributed as dist
+            return dist.get_world_size()
+        return 1
 
     def fence(self):
         if not self.dry:
@@ -224,7 +270,8 @@ def strong_scaling(args, job, model, tokenizer_mask, n_draw):
         rate = N * args.steps / elapsed
         out = {
             "metric": f"sequences/sec, OA_DM_{args.model} len-{L} sampling", "value": rate, "unit": "sequences/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": job.group_size(), "rccl_ranks": job.group_size(), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": f"OA_DM_{args.model} unconditional generate_oaardm, {N} sequences sharded over "
@@ -284,6 +331,8 @@ def main():
                          "(D3PM_BLOSUM, every Q_t transition step of generate_d3pm per batch)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spot-check", action="store_true",
+                    help="skip the check of the last timed batch against the CPU oracle (after the timed region)")
     ap.add_argument("--probe-every", type=int, default=64)
     ap.add_argument("--total-sequences", type=int, default=0,
                     help="strong-scaling form (BASELINE config 4): a step samples this many sequences in total, sharded "
@@ -316,6 +365,7 @@ def main():
         else:
             loader = pretrained.OA_DM_640M if args.model == "640M" else pretrained.OA_DM_38M
             model, _, tokenizer, _ = loader(random_init=True)
+            sharpen_decoder(model, DECODER_SCALE)
         model.precision = args.precision
         model.use_graph = not args.no_graph
         mask_id, n_draw = tokenizer.mask_id, len(tokenizer.all_aas) - 6
@@ -384,10 +434,11 @@ def main():
             "metric": f"sequences/sec, {name} len-{L} sampling",
             "value": world * B * args.steps / elapsed,
             "unit": "sequences/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": job.group_size(), "rccl_ranks": job.group_size(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision,
+            "data": "synthetic" + ("" if d3pm or job.dry else f" (seed-0 default init, decoder weight x {DECODER_SCALE:g})"),
             "config": {"workload": f"{name} unconditional {'generate_d3pm' if d3pm else 'generate_oaardm'}, "
                                    f"batch {B} per GPU, seq_len {L} ({n_fwd} diffusion steps per batch), hipGraph replay "
                                    f"{'off' if args.no_graph else 'on'}"
@@ -442,6 +493,10 @@ def main():
                                                "frac": gbs / PEAK_HBM_GBS, "weight_bytes_per_step": wbytes}
             if world == 1 and not args.no_cpu_baseline and not d3pm:  # the CPU leg times the metric's OA-DM loop
                 out["cpu_baseline"] = cpu_baseline(L)
+            if not d3pm and not args.no_spot_check:
+                # correctness evidence of THIS run, outside the timed region: rank 0's last timed batch against the oracle
+                out["oracle_spot_check"] = oracle_spot_check(model, args.model, samples[-1], orders[-1], uniforms[-1].cpu(),
+                                                             args.precision)
         print(json.dumps(out), flush=True)
     job.close()
 

@@ -19,7 +19,7 @@ OPTIONS = {"prune": 0, "min_tuned_tiles": 1, "split_target": 2, "incremental": 3
 SYMBOLS = ("ed_abi_version", "ed_last_error", "ed_model_create", "ed_model_destroy", "ed_model_load_tensor",
            "ed_model_commit", "ed_model_num_params", "ed_forward", "ed_forward_collect", "ed_score_nll", "ed_ar_sample", "ed_oadm_sample",
            "ed_d3pm_sample", "ed_model_set_option", "ed_probe_config", "ed_probe_read", "ed_debug_gemm",
-           "ed_debug_ln_act", "ed_debug_set_stamp_buffer", "ed_debug_gemm_splitk_noalloc", "ed_model_check_errors")
+           "ed_debug_ln_act", "ed_debug_set_stamp_buffer", "ed_debug_gemm_splitk_noalloc", "ed_model_check_errors", "ed_model_get_config", "ed_ar_sample_scaffold")
 
 
 class EdConfig(C.Structure):
@@ -61,6 +61,7 @@ def load():
     lib.ed_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp]
     lib.ed_forward_collect.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp]
     lib.ed_ar_sample.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
+    lib.ed_ar_sample_scaffold.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
     lib.ed_score_nll.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]
     lib.ed_oadm_sample.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
     lib.ed_d3pm_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
@@ -69,6 +70,7 @@ def load():
                                                  i32, vp]
     lib.ed_debug_ln_act.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.ed_model_check_errors.argtypes = [vp, vp, i32]
+    lib.ed_model_get_config.argtypes = [vp, C.POINTER(EdConfig)]
     lib.ed_probe_config.argtypes = [vp, i32]
     lib.ed_debug_set_stamp_buffer.argtypes = [vp, i64]
     lib.ed_model_set_option.argtypes = [vp, i32, i32]

@@ -120,6 +120,8 @@ struct ed_model {
   // never change), a step computes one new row per sequence and layer.  Car[k]: [B][conv_pitch][d_hidden].
   std::vector<DevBuf> Car;
   int ar_B = 0, ar_L = 0, ar_prec = -1;
+  DevBuf ar_keep, ar_ndraw;   // ed_ar_sample_scaffold: given positions (L bytes), classes per step (n_steps ints)
+  bool ar_forced = false;     // the current autoregressive call uses them
   // LayerNorm fused into the tuned kernels' epilogues (ED_OPT_FUSE_LN, ln_epilogue.hpp): exchange buffer for the per-row
   // partial statistics, arrival counters (one array per GEMM of the block: a counter must always see the same number of
   // column tiles), and a host-visible error word the kernels raise when a bounded wait runs out.
@@ -509,7 +511,7 @@ int ensure_workspace(ed_model* m, int B, int L, int prec, hipStream_t s) {
 
 // Variants of a step: every position with no state kept (forward, D3PM), every position while filling the caches of
 // the incremental layers (first OA-DM step of a call), and the incremental step proper.
-enum { STEP_PLAIN = 0, STEP_FILL = 1, STEP_INCR = 2, STEP_AR = 3 };
+enum { STEP_PLAIN = 0, STEP_FILL = 1, STEP_INCR = 2, STEP_AR = 3, STEP_AR_SCAFFOLD = 4 };
 
 // One incremental leading layer k (STEP_INCR): the rows within r_{k-1} of the changed position go through
 // LN1 / PFF1 / LN2 into the cached convolution input, the rows within r_k through conv / LN3 / PFF2 into the cached
@@ -778,7 +780,9 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   LAUNCH_TRY(pr.begin());
   LAUNCH_TRY(launch_final_oadm(x, 1, 30, m->last_g, m->last_b, m->dec_w, m->dec_b, m->tok.as<int64_t>(),
                                m->order.as<int>(), m->uni.as<float>(), m->state.as<StepState>(), probs, B, L, D, n, s,
-                               /*write_shift=*/1, /*advance=*/B <= ED_ADVANCE_IN_TAIL_MAX_B));
+                               /*write_shift=*/1, /*advance=*/B <= ED_ADVANCE_IN_TAIL_MAX_B,
+                               m->ar_forced ? m->ar_ndraw.as<int>() : nullptr,
+                               m->ar_forced ? m->ar_keep.as<uint8_t>() : nullptr));
   LAUNCH_TRY(pr.end(ED_K_FINAL, 2.0 * B * n * D, (double)B * D * 4.0));
   if (B > ED_ADVANCE_IN_TAIL_MAX_B) LAUNCH_TRY(launch_advance_step(m->state.as<StepState>(), s));
   return ED_OK;
@@ -854,8 +858,8 @@ int run_loop(ed_model* m, int mode, int B, int L, int n, int n_steps, int prec, 
   const bool inc = mode == MODE_OADM && m->n_inc > 0;
   hipGraphExec_t exec_first = nullptr, exec_rest = nullptr;
   if (use_graph && !traced) {
-    int rc = get_graph(m, mode, mode == MODE_AR ? STEP_AR : inc ? STEP_FILL : STEP_PLAIN, B, L, n, prec, nullptr, nullptr,
-                       &exec_first);
+    int rc = get_graph(m, mode, mode == MODE_AR ? (m->ar_forced ? STEP_AR_SCAFFOLD : STEP_AR) : inc ? STEP_FILL : STEP_PLAIN,
+                       B, L, n, prec, nullptr, nullptr, &exec_first);
     if (rc) return rc;
     exec_rest = exec_first;
     if (inc && n_steps > 1 && (rc = get_graph(m, mode, STEP_INCR, B, L, n, prec, nullptr, nullptr, &exec_rest))) return rc;
@@ -1048,6 +1052,12 @@ int ed_model_commit(ed_model* m) {
 
 int64_t ed_model_num_params(const ed_model* m) { return m ? m->n_params : 0; }
 
+int ed_model_get_config(const ed_model* m, ed_config* out) {
+  if (!m || !out) return fail(ED_EINVAL, "null argument");
+  *out = m->cfg;
+  return ED_OK;
+}
+
 int ed_forward_collect(ed_model* m, const int64_t* tokens_dev, const int64_t* timesteps_dev, int B, int L,
                        float* logits_dev, float* acts_dev, int precision, void* stream) {
   int rc = check_shape(m, B, L, precision);
@@ -1142,8 +1152,9 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
   return ED_OK;
 }
 
-int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, int B, int L, int n_steps, int n_draw,
-                 float* probs_dev, int precision, int use_graph, void* stream) {
+static int ar_sample_impl(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, const uint8_t* keep_dev,
+                          const int32_t* n_draw_step_dev, int B, int L, int n_steps, int n_draw, float* probs_dev,
+                          int precision, int use_graph, void* stream) {
   int rc = check_shape(m, B, L, precision);
   if (rc) return rc;
   const ed_config& c = m->cfg;
@@ -1179,13 +1190,38 @@ int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, in
     HIP_TRY(m->uni.ensure((size_t)n_steps * B * 4));
     if (m->order.bytes != ob || m->uni.bytes != ub) m->drop_graphs();
   }
+  m->ar_forced = keep_dev != nullptr;
+  if (m->ar_forced) {  // model-owned copies: the captured graph sees stable pointers
+    const size_t kb = m->ar_keep.bytes, nb = m->ar_ndraw.bytes;
+    HIP_TRY(m->ar_keep.ensure((size_t)L));
+    HIP_TRY(m->ar_ndraw.ensure((size_t)n_steps * 4));
+    if (m->ar_keep.bytes != kb || m->ar_ndraw.bytes != nb) m->drop_graphs();
+    HIP_TRY(hipMemcpyAsync(m->ar_keep.p, keep_dev, (size_t)L, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m->ar_ndraw.p, n_draw_step_dev, (size_t)n_steps * 4, hipMemcpyDeviceToDevice, s));
+  }
   LAUNCH_TRY(launch_prepare_order(nullptr, m->order.as<int>(), n_steps, L, m->ln_err_dev, s));  // step i extends position i
   HIP_TRY(hipMemcpyAsync(m->uni.p, uniforms_dev, (size_t)n_steps * B * 4, hipMemcpyDeviceToDevice, s));
   LAUNCH_TRY(launch_prepare_ids(tokens_dev, m->tok.as<int64_t>(), (long)B * L, c.n_tokens, m->ln_err_dev, ED_AERR_TOKEN, s));
   LAUNCH_TRY(launch_init_state(m->state.as<StepState>(), 0, 0, s));
-  if ((rc = run_loop(m, MODE_AR, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s))) return rc;
+  rc = run_loop(m, MODE_AR, B, L, n_draw, n_steps, precision, use_graph, probs_dev, nullptr, s);
+  m->ar_forced = false;
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(tokens_dev, m->tok.p, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s));
   return ED_OK;
+}
+
+int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, int B, int L, int n_steps, int n_draw,
+                 float* probs_dev, int precision, int use_graph, void* stream) {
+  return ar_sample_impl(m, tokens_dev, uniforms_dev, nullptr, nullptr, B, L, n_steps, n_draw, probs_dev, precision,
+                        use_graph, stream);
+}
+
+int ed_ar_sample_scaffold(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, const uint8_t* given_dev,
+                          const int32_t* n_draw_step_dev, int B, int L, int n_steps, int n_draw_max, float* probs_dev,
+                          int precision, int use_graph, void* stream) {
+  if (!given_dev || !n_draw_step_dev) return fail(ED_EINVAL, "null given/n_draw_step pointer");
+  return ar_sample_impl(m, tokens_dev, uniforms_dev, given_dev, n_draw_step_dev, B, L, n_steps, n_draw_max, probs_dev,
+                        precision, use_graph, stream);
 }
 
 int ed_d3pm_sample(ed_model* m, int64_t* tokens_dev, const double* Q_dev, const double* Qbar_dev,

@@ -587,20 +587,29 @@ __global__ __launch_bounds__(64 * OADM_WAVES) void final_oadm_kernel(const float
                                                         const float* beta, const float* dec_w, const float* dec_b,
                                                         int64_t* tokens, const int* __restrict__ order,
                                                         const float* __restrict__ uniforms, StepState* state,
-                                                        float* probs, int B, int L, int D, int n_draw,
-                                                        int x_rows_per_seq, int x_shift, int write_shift, int advance) {
+                                                        float* probs, int B, int L, int D, int n_draw_max,
+                                                        int x_rows_per_seq, int x_shift, int write_shift, int advance,
+                                                        const int* __restrict__ n_draw_step,
+                                                        const uint8_t* __restrict__ keep) {
   __shared__ float logits[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
   const int step = state->step;
   const int pos = order[step];
   const long row = (long)b * L + pos;
   const long xrow = (long)b * x_rows_per_seq + (pos >> x_shift);
-  row_logits_spread<NCH>(X, xrow, D, lane, wave, gamma, beta, dec_w, dec_b, n_draw, logits);
+  row_logits_spread<NCH>(X, xrow, D, lane, wave, gamma, beta, dec_w, dec_b, n_draw_max, logits);
   __syncthreads();
   if (wave != 0) return;
+  // classes of this step's draw: the first n_draw_step[step] logits (scaffolded autoregressive sampling changes the
+  // range along the sequence, conditional_generation.py:549-550,562), clamped into [1, n_draw_max]
+  int n_draw = n_draw_max;
+  if (n_draw_step != nullptr) {
+    const int n = n_draw_step[step];
+    n_draw = n < 1 ? 1 : (n > n_draw_max ? n_draw_max : n);
+  }
   const float logit = lane < n_draw ? logits[lane] : 0.f;
   const float p = lane_softmax(logit, lane, n_draw);
-  if (probs != nullptr && lane < n_draw) probs[((long)step * B + b) * n_draw + lane] = p;
+  if (probs != nullptr && lane < n_draw_max) probs[((long)step * B + b) * n_draw_max + lane] = lane < n_draw ? p : 0.f;
   // inverse CDF: index = #{k : cdf[k] <= u * cdf[n-1]}, cdf = left-to-right fp32 running sum
   float cdf = 0.f, mycdf = 0.f;
   for (int k = 0; k < n_draw; ++k) {
@@ -612,7 +621,9 @@ __global__ __launch_bounds__(64 * OADM_WAVES) void final_oadm_kernel(const float
   int idx = __popcll(below);
   if (idx > n_draw - 1) idx = n_draw - 1;
   // write_shift = 1 (autoregressive steps, generate.py:241-244): the draw from position pos is the NEXT token
-  if (lane == 0 && pos + write_shift < L) tokens[row + write_shift] = idx;
+  // keep: positions whose token is given (a motif spliced into the sequence): the draw is made and dropped
+  const bool given = keep != nullptr && pos + write_shift < L && keep[pos + write_shift] != 0;
+  if (lane == 0 && pos + write_shift < L && !given) tokens[row + write_shift] = idx;
   // the step counter moves on once the LAST workgroup is done: each one read it when it started, so none reads the
   // new value (saves the one-thread advance launch at the end of every step)
   if (advance && lane == 0) {
@@ -868,12 +879,14 @@ hipError_t launch_final_nll(const float* X, const float* gamma, const float* bet
 hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
                              const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
                              const float* uniforms, StepState* state, float* probs, int B, int L, int D,
-                             int n_draw, hipStream_t stream, int write_shift, bool advance) {
+                             int n_draw, hipStream_t stream, int write_shift, bool advance, const int* n_draw_step,
+                             const uint8_t* keep) {
   if (D % 4 != 0 || n_draw > 64 || n_draw < 1 || B <= 0) return hipErrorInvalidValue;
   const dim3 grid(B), block(64 * OADM_WAVES);
 #define ED_CALL(N)                                                                                             \
   hipLaunchKernelGGL((final_oadm_kernel<N>), grid, block, 0, stream, X, gamma, beta, dec_w, dec_b, tokens, order, \
-                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift, write_shift, advance ? 1 : 0)
+                     uniforms, state, probs, B, L, D, n_draw, x_rows_per_seq, x_shift, write_shift, advance ? 1 : 0, \
+                     n_draw_step, keep)
   ED_NCH_DISPATCH(D, ED_CALL);
 #undef ED_CALL
   return hipGetLastError();

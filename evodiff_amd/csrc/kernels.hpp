@@ -199,10 +199,14 @@ hipError_t launch_final_logits(const float* X, const float* gamma, const float* 
 
 // OA-DM step tail (generate.py:198-211): one categorical draw per sequence at position pos = order[step].
 // X holds x_rows_per_seq rows per sequence; the row of position pos is pos >> x_shift.
+// n_draw_step (may be null): the draw of step s is over the first n_draw_step[s] classes (<= n_draw; probs rows keep
+// n_draw entries, zero beyond).  keep (may be null): L bytes, a non-zero byte marks a position whose token is given -
+// the step that would write it leaves it alone (generate_autoreg_scaffold's motif, conditional_generation.py:552-557).
 hipError_t launch_final_oadm(const float* X, int x_rows_per_seq, int x_shift, const float* gamma, const float* beta,
                              const float* dec_w, const float* dec_b, int64_t* tokens, const int* order,
                              const float* uniforms, StepState* state, float* probs, int B, int L, int D,
-                             int n_draw, hipStream_t stream, int write_shift = 0, bool advance = false);
+                             int n_draw, hipStream_t stream, int write_shift = 0, bool advance = false,
+                             const int* n_draw_step = nullptr, const uint8_t* keep = nullptr);
 // Batches up to this size advance the step counter inside the OA-DM step tail (the workgroup that finishes last does
 // it: every workgroup has read the counter by then) instead of a launch of its own; larger ones would queue on the
 // ticket word for longer than that launch takes.

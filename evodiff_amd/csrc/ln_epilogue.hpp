@@ -13,7 +13,14 @@
 // in a fixed order, so the result does not depend on timing, tile height or dispatch order.
 //
 // Exchange (cdna_hip_programming.md Guideline 16; MI355X_MICROARCH.md "Valid forms", first row of the sc1 table).  The
-// protocol assumes nothing about dispatch order or workgroup -> XCD placement:
+// memory protocol assumes nothing about workgroup -> XCD placement or about which partner arrives first.  Forward
+// progress does rest on one assumption: a waiting workgroup's partners must become resident while it spins.  The
+// tiles_n workgroups of a row tile have block ids at most 8 * (tiles_n - 1) <= 24 apart (tile order of the tile bodies),
+// and the hardware dispatches the workgroups of a launch in block-id order, so the workgroup with the lowest id that
+// is still waiting always has every partner dispatched already (or next in line as soon as any workgroup ends): the
+// resident set is a contiguous window of ids that moves forward.  A dispatcher that did not go in id order could strand
+// a launch with more workgroups than fit on the chip; the bounded poll below then turns that into a reported error.
+// The hand-off itself:
 //   producer: each of the first BM threads stores its row's 8-byte {mean, M2} with a write-through (sc1) store; every
 //             storing wave drains its stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds 1 to the row tile's
 //             counter (agent-scope atomic);
@@ -36,7 +43,8 @@ typedef __attribute__((address_space(1))) unsigned long long ln_gu64;
 typedef __attribute__((address_space(1))) unsigned int ln_gu32;
 
 constexpr float LN_FUSED_EPS = 1e-5f;            // nn.LayerNorm default (as elementwise.hip)
-constexpr unsigned long long LN_SPIN_TICKS = 5000000ull;  // 50 ms of the 100-MHz clock
+constexpr unsigned long long LN_SPIN_TICKS = 200000000ull;  // 2 s of the 100-MHz clock: far beyond any delay CU contention
+                                                          // can cause (a launch is ~0.2 ms), short enough not to look hung
 
 // x * sigmoid(x (a + b x^2 + c x^4)): the fit of the exact-erf GELU the stand-alone bf16 LayerNorm uses
 // (elementwise.hip, 2.6e-5 absolute), two elements at a time.

@@ -26,13 +26,35 @@ void want(const at::Tensor& t, at::ScalarType dtype, const char* name) {
   TORCH_CHECK(t.scalar_type() == dtype && t.is_contiguous(), "evodiff_amd: ", name, " must be contiguous ", dtype);
 }
 
+ed_config config_of(int64_t handle) {
+  ed_config c;
+  check(ed_model_get_config(as_model(handle), &c));
+  return c;
+}
+
+// (B, L) of a token tensor; every other tensor of a call is checked against them and against the model's own
+// hyper-parameters, so that a caller's mistake is a RuntimeError here and never an out-of-bounds access on the device
+void batch_shape(const at::Tensor& tokens, int64_t* B, int64_t* L) {
+  TORCH_CHECK(tokens.dim() == 2 && tokens.size(0) > 0 && tokens.size(1) > 0, "evodiff_amd: tokens must be (batch, length)");
+  *B = tokens.size(0);
+  *L = tokens.size(1);
+}
+
+void want_timesteps(const ed_config& c, const at::Tensor& timesteps, int64_t B) {
+  want(timesteps, at::kLong, "timesteps");
+  TORCH_CHECK(c.timesteps == 0 || timesteps.numel() == B, "evodiff_amd: timesteps must hold one entry per sequence (", B,
+              "), got ", timesteps.numel());
+}
+
 // ByteNetLMTime.forward(x, y) (evodiff/model.py:170-173): (B, L) int64 tokens, (B,) int64 timesteps -> (B, L, n_tokens) fp32
 at::Tensor forward(int64_t handle, const at::Tensor& tokens, const at::Tensor& timesteps, int64_t n_tokens,
                    int64_t precision) {
   want(tokens, at::kLong, "tokens");
-  want(timesteps, at::kLong, "timesteps");
-  TORCH_CHECK(tokens.dim() == 2, "evodiff_amd: tokens must be (batch, length)");
-  const int64_t B = tokens.size(0), L = tokens.size(1);
+  int64_t B, L;
+  batch_shape(tokens, &B, &L);
+  const ed_config c = config_of(handle);
+  want_timesteps(c, timesteps, B);
+  TORCH_CHECK(n_tokens == c.n_tokens, "evodiff_amd: n_tokens = ", n_tokens, " but the model has ", c.n_tokens, " (it sizes the logits)");
   at::Tensor logits = at::empty({B, L, n_tokens}, tokens.options().dtype(at::kFloat));
   check(ed_forward(as_model(handle), tokens.data_ptr<int64_t>(), timesteps.data_ptr<int64_t>(), (int)B, (int)L,
                    logits.data_ptr<float>(), (int)precision, current_stream(tokens)));
@@ -45,7 +67,9 @@ at::Tensor oadm_sample_(int64_t handle, at::Tensor tokens, const at::Tensor& ord
   want(tokens, at::kLong, "tokens");
   want(order, at::kInt, "order");
   want(uniforms, at::kFloat, "uniforms");
-  const int64_t B = tokens.size(0), L = tokens.size(1), n_steps = order.numel();
+  int64_t B, L;
+  batch_shape(tokens, &B, &L);
+  const int64_t n_steps = order.numel();
   TORCH_CHECK(uniforms.numel() == n_steps * B, "evodiff_amd: uniforms must be (n_steps, B)");
   check(ed_oadm_sample(as_model(handle), tokens.data_ptr<int64_t>(), order.data_ptr<int32_t>(), uniforms.data_ptr<float>(),
                        (int)B, (int)L, (int)n_steps, (int)n_draw, nullptr, (int)precision, use_graph ? 1 : 0,
@@ -62,7 +86,9 @@ at::Tensor d3pm_sample_(int64_t handle, at::Tensor tokens, const at::Tensor& Q, 
   want(Qbar, at::kDouble, "Qbar");
   want(uniforms, at::kFloat, "uniforms");
   TORCH_CHECK(Q.dim() == 3 && Q.size(1) == K && Q.size(2) == K && Qbar.sizes() == Q.sizes(), "evodiff_amd: Q / Qbar must be (timesteps, K, K)");
-  const int64_t B = tokens.size(0), L = tokens.size(1);
+  int64_t B, L;
+  batch_shape(tokens, &B, &L);
+  TORCH_CHECK(Q.size(0) == config_of(handle).timesteps, "evodiff_amd: Q / Qbar must hold one matrix per timestep of the model");
   TORCH_CHECK(uniforms.numel() == Q.size(0) * B * L, "evodiff_amd: uniforms must be (timesteps, B, L)");
   check(ed_d3pm_sample(as_model(handle), tokens.data_ptr<int64_t>(), Q.data_ptr<double>(), Qbar.data_ptr<double>(),
                        uniforms.data_ptr<float>(), (int)B, (int)L, (int)K, (int)t_start, (int)n_steps, nullptr,
@@ -74,10 +100,15 @@ at::Tensor d3pm_sample_(int64_t handle, at::Tensor tokens, const at::Tensor& Q, 
 at::Tensor score_nll(int64_t handle, const at::Tensor& tokens, const at::Tensor& timesteps, const at::Tensor& targets,
                      const c10::optional<at::Tensor>& select, int64_t n_classes, int64_t precision) {
   want(tokens, at::kLong, "tokens");
-  want(timesteps, at::kLong, "timesteps");
   want(targets, at::kLong, "targets");
-  if (select.has_value()) want(*select, at::kByte, "select");
-  const int64_t B = tokens.size(0), L = tokens.size(1);
+  int64_t B, L;
+  batch_shape(tokens, &B, &L);
+  want_timesteps(config_of(handle), timesteps, B);
+  TORCH_CHECK(targets.sizes() == tokens.sizes(), "evodiff_amd: targets must have the shape of tokens");
+  if (select.has_value()) {
+    want(*select, at::kByte, "select");
+    TORCH_CHECK(select->numel() == B * L, "evodiff_amd: select must hold one byte per position (", B * L, ")");
+  }
   at::Tensor nll = at::empty({B, L}, tokens.options().dtype(at::kFloat));
   check(ed_score_nll(as_model(handle), tokens.data_ptr<int64_t>(), timesteps.data_ptr<int64_t>(), targets.data_ptr<int64_t>(),
                      select.has_value() ? select->data_ptr<uint8_t>() : nullptr, (int)B, (int)L, (int)n_classes,

@@ -17,8 +17,13 @@ import torch
 from .utils import Tokenizer  # noqa: F401  (re-exported like the reference module)
 
 
-def _strings(tokenizer, sample):
+def _strings(tokenizer, sample, model=None):
+    """Untokenised rows of ``sample``.  The copy to the host synchronises the stream, so this is also where a sampler
+    reports what its kernels raised asynchronously (clamped out-of-range data, a fused-LayerNorm exchange that timed
+    out): with ``model`` given the offending call itself raises, not the next one."""
     host = sample.detach().cpu().numpy()
+    if model is not None and hasattr(model, "check_errors"):
+        model.check_errors(synchronize=False)
     return [tokenizer.untokenize(row) for row in host]
 
 
@@ -69,7 +74,7 @@ def generate_oaardm(model, tokenizer, seq_len, penalty=None, batch_size=3, devic
                     p2[rows, p_sample[rows]] /= penalty
                     p_sample = torch.where(repeat, _inverse_cdf(p2, uniforms[n_steps + s]), p_sample)
                 sample[:, i] = p_sample
-    untokenized = _strings(tokenizer, sample)
+    untokenized = _strings(tokenizer, sample, model)
     return sample, untokenized
 
 
@@ -98,7 +103,7 @@ def generate_oaardm_order_opt(model, tokenizer, seq_len, penalty=None, batch_siz
             pos = torch.div(idx, p.shape[-1], rounding_mode='trunc')
             tok = _inverse_cdf(p[0].index_select(0, pos.reshape(1)), uniforms[s].reshape(1))
             sample.index_copy_(1, pos.reshape(1), tok.reshape(1, 1).expand(batch_size, 1))
-    return sample, _strings(tokenizer, sample)
+    return sample, _strings(tokenizer, sample, model)
 
 
 def generate_autoreg(model, tokenizer, samples=100, batch_size=1, max_seq_len=1024, device='cuda', *, uniforms=None):
@@ -119,6 +124,7 @@ def generate_autoreg(model, tokenizer, samples=100, batch_size=1, max_seq_len=10
             sample = torch.full((nb, max_seq_len + 1), start, dtype=torch.long, device=device)
             model.ar_sample(sample, uniforms[s0:s0 + nb].t().contiguous(), n_steps=max_seq_len)
             host = sample.cpu()
+            model.check_errors(synchronize=False)       # (the copy above synchronised the stream)
             for row in host:
                 hits = (row[1:] == stop).nonzero()
                 end = int(hits[0]) + 2 if len(hits) else max_seq_len + 1      # one past the STOP / the last token
@@ -140,7 +146,7 @@ def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, batch_size=3, 
         uniforms = torch.rand((timesteps, batch_size, seq_len), dtype=torch.float32, device=device)
     with torch.no_grad():
         model.d3pm_sample(sample, Q, Q_bar, torch.as_tensor(uniforms), tokenizer.K, t_start=timesteps - 1)
-    untokenized = _strings(tokenizer, sample)
+    untokenized = _strings(tokenizer, sample, model)
     print("final seq", untokenized)
     return sample, untokenized
 

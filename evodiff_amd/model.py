@@ -302,9 +302,12 @@ class ByteNetLMTime(nn.Module):
                                           int(self.use_graph), stream))
         return probs
 
-    def ar_sample(self, sample, uniforms, n_steps=None, n_draw=None, return_probs=False):
+    def ar_sample(self, sample, uniforms, n_steps=None, n_draw=None, return_probs=False, given=None, n_draw_steps=None):
         """Loop of generate_autoreg (generate.py:238-244) on the GPU for a causal model: ``sample`` (B, L) holds the
-        START token in column 0; columns 1 .. n_steps are filled in place, one cached-convolution step each."""
+        START token in column 0; columns 1 .. n_steps are filled in place, one cached-convolution step each.
+        ``given`` (L,) bool + ``n_draw_steps`` (n_steps,) int: the scaffolded form (``ed_ar_sample_scaffold``,
+        conditional_generation.py:545-572) - columns marked in ``given`` keep the token they hold, step s draws over
+        the first ``n_draw_steps[s]`` classes."""
         handle = self.hip_handle(sample.device)
         lib = _lib.load()
         B, L = sample.shape
@@ -316,10 +319,22 @@ class ByteNetLMTime(nn.Module):
             raise ValueError("uniforms must be (n_steps, B)")
         probs = torch.empty((n_steps, B, n_draw), dtype=torch.float32, device=sample.device) if return_probs else None
         stream = torch.cuda.current_stream(sample.device).cuda_stream
+        if (given is None) != (n_draw_steps is None):
+            raise ValueError("given and n_draw_steps go together")
         with torch.cuda.device(sample.device):
-            _lib.check(lib.ed_ar_sample(handle, sample.data_ptr(), uniforms.data_ptr(), B, L, n_steps, n_draw,
-                                        probs.data_ptr() if return_probs else None, self._prec(),
-                                        int(self.use_graph), stream))
+            if given is None:
+                _lib.check(lib.ed_ar_sample(handle, sample.data_ptr(), uniforms.data_ptr(), B, L, n_steps, n_draw,
+                                            probs.data_ptr() if return_probs else None, self._prec(),
+                                            int(self.use_graph), stream))
+            else:
+                given = torch.as_tensor(given).to(device=sample.device).ne(0).to(torch.uint8).contiguous()
+                n_draw_steps = torch.as_tensor(n_draw_steps).to(device=sample.device, dtype=torch.int32).contiguous()
+                if given.numel() != L or n_draw_steps.numel() != n_steps:
+                    raise ValueError("given must hold L entries and n_draw_steps n_steps")
+                _lib.check(lib.ed_ar_sample_scaffold(handle, sample.data_ptr(), uniforms.data_ptr(), given.data_ptr(),
+                                                     n_draw_steps.data_ptr(), B, L, n_steps, n_draw,
+                                                     probs.data_ptr() if return_probs else None, self._prec(),
+                                                     int(self.use_graph), stream))
         return probs
 
     def d3pm_sample(self, sample, Q, Q_bar, uniforms, K, t_start=None, n_steps=None, return_post=False):

@@ -9,6 +9,8 @@ additive: checkpoints are never downloaded (no network) — pass ``path_to_check
 """
 import json
 import os
+import re
+import warnings
 
 import torch
 
@@ -42,29 +44,47 @@ def load_sequence_checkpoint(model_name, config_path, diffusion_timesteps, token
     msd = state_dict["model_state_dict"]
     # checkpoints were saved from DistributedDataParallel: strip the "module." prefix (pretrained.py:47-51)
     msd = {(k.split("module.")[1] if k.startswith("module.") else k): v for k, v in msd.items()}
+    if causal:
+        msd = {_CAUSAL_NESTED.sub(r"\1.\2", k): v for k, v in msd.items()}
     model.load_state_dict(msd)
     check_mask_embedding(model, tokenizer, source=path_to_checkpoints or model_name)
     return model, tokenizer
 
 
-def check_mask_embedding(model, tokenizer, source="checkpoint"):
+# Key layout of the causal convolution.  This build holds it as a Conv1d subclass (keys ``...layers.i.conv.weight``, like
+# MaskedConv1d); sequence_models' MaskedCausalConv1d may instead WRAP its Conv1d (``...layers.i.conv.conv.weight``) -
+# recalled, not verifiable offline - so a causal checkpoint is accepted in either layout.
+_CAUSAL_NESTED = re.compile(r"^(embedder\.layers\.\d+\.conv)\.conv\.(weight|bias)$")
+
+
+def check_mask_embedding(model, tokenizer, source="checkpoint", strict=None):
     """Alphabet self-check on LOADED weights.  The reference builds its embedding with
     ``padding_idx=tokenizer.mask_id`` (pretrained.py:39-40, model.py:97): that row is zero at init and never receives a
     gradient, so a trained checkpoint has ``embedder.embedder.weight[mask_id] == 0`` - and no other all-zero row.  The
     order of the last four special tokens of ``MSA_ALPHABET`` / ``PROTEIN_ALPHABET`` in ``evodiff_amd/constants.py``
     is restated from the third-party ``sequence_models.constants`` from memory; if it were wrong, the zero row of a real
-    checkpoint would sit at another index and every mask token would be embedded as some other symbol.  Raises
-    ``ValueError`` naming the alphabet table instead of sampling garbage."""
+    checkpoint would sit at another index and every mask token would be embedded as some other symbol.
+    The reference's loader accepts any state dict (pretrained.py:43-52), so this check only REFUSES the one case that
+    proves the table wrong - the mask row is not zero while some other row is (``ValueError`` naming the table).  Anything
+    else that is merely unexpected (no zero row at all, e.g. a fine-tuned checkpoint whose padding row moved off zero;
+    further zero rows besides the mask row) loads with a warning.  ``strict=True`` (or ``$EVODIFF_AMD_STRICT_ALPHABET=1``)
+    turns the warnings into errors as well; ``strict=False`` silences the check."""
+    if strict is None:
+        strict = {"1": True, "0": False}.get(os.environ.get("EVODIFF_AMD_STRICT_ALPHABET", ""), None)
+    if strict is False:
+        return
     weight = model.state_dict()["embedder.embedder.weight"]
     mask_id = int(tokenizer.mask_id)
     zero_rows = [int(i) for i in torch.nonzero(weight.abs().sum(dim=1) == 0).flatten()]
-    if zero_rows != [mask_id]:
-        raise ValueError(
-            "%s: embedder.embedder.weight has all-zero rows %s but the tokenizer's mask_id is %d. A checkpoint trained "
-            "with padding_idx=mask_id keeps exactly that row at zero, so the token order in evodiff_amd/constants.py "
-            "(MSA_ALPHABET / PROTEIN_ALPHABET: gap, stop, mask, start, pad) does not match the alphabet the checkpoint "
-            "was trained with; fix that table (or the checkpoint is not an EvoDiff sequence model)."
-            % (source, zero_rows, mask_id))
+    if zero_rows == [mask_id]:
+        return
+    message = ("%s: embedder.embedder.weight has all-zero rows %s but the tokenizer's mask_id is %d. A checkpoint trained "
+               "with padding_idx=mask_id keeps exactly that row at zero; if the token order in evodiff_amd/constants.py "
+               "(MSA_ALPHABET / PROTEIN_ALPHABET: gap, stop, mask, start, pad) did not match the alphabet the checkpoint "
+               "was trained with, the zero row would sit elsewhere." % (source, zero_rows, mask_id))
+    if strict or (zero_rows and mask_id not in zero_rows):
+        raise ValueError(message + " Fix that table (or the checkpoint is not an EvoDiff sequence model).")
+    warnings.warn(message)
 
 
 def _d3pm(model_name, config, blosum, return_all, path_to_checkpoints, random_init):

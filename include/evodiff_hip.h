@@ -94,6 +94,10 @@ int ed_model_load_tensor(ed_model* m, const char* key, const float* host, int64_
 int ed_model_commit(ed_model* m);
 /* Number of parameters packed (for cross-checks against 37,890,327 / 642,951,959). */
 int64_t ed_model_num_params(const ed_model* m);
+/* The hyper-parameters the handle was created with (the attributes a caller of the reference reads off the module:
+ * model.embedder.timesteps, decoder width, ...): lets a binding size and check its buffers against the model instead of
+ * trusting its own caller (csrc/torch_ops.cpp). */
+int ed_model_get_config(const ed_model* m, ed_config* out);
 
 /* Replaces: ByteNetLMTime.forward(x, y, input_mask=None) (evodiff/model.py:170-173).
  * tokens_dev int64 (B, L); timesteps_dev int64 (B,) (ignored when cfg.timesteps == 0);
@@ -141,6 +145,16 @@ int ed_oadm_sample(ed_model* m, int64_t* tokens_dev, const int32_t* order_dev, c
  * ED_ESTATE unless cfg.causal = 1 and cfg.timesteps = 0. */
 int ed_ar_sample(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, int B, int L, int n_steps, int n_draw,
                  float* probs_dev, int precision, int use_graph, void* stream);
+
+/* Replaces: the loop of generate_autoreg_scaffold (evodiff/conditional_generation.py:545-572): ed_ar_sample with a motif
+ * spliced into the growing sequence.  given_dev: L bytes, a non-zero byte at position l means tokens_dev[b][l] is given
+ * (the motif, and START at position 0): the step that would draw it runs - the caches of every layer need its row - and
+ * its draw is dropped.  n_draw_step_dev int32 (n_steps,): step s draws over the first n_draw_step[s] classes (the
+ * reference excludes STOP and the specials until the last motif residue is placed, :549-550,562), clamped into
+ * [1, n_draw_max]; probs_dev rows hold n_draw_max entries, zero beyond the step's range.  Otherwise as ed_ar_sample. */
+int ed_ar_sample_scaffold(ed_model* m, int64_t* tokens_dev, const float* uniforms_dev, const uint8_t* given_dev,
+                          const int32_t* n_draw_step_dev, int B, int L, int n_steps, int n_draw_max, float* probs_dev,
+                          int precision, int use_graph, void* stream);
 
 /* Replaces: the loop of generate_d3pm (evodiff/generate.py:274-298).
  * tokens_dev int64 (B, L) in/out = x_t on entry; Q_dev / Qbar_dev fp64 (timesteps, K, K) as returned by

@@ -381,6 +381,67 @@ def generate_oaardm_ref(model, seq_len, batch_size, order, uniforms, trace=None,
     return sample
 
 
+@torch.no_grad()
+def generate_oaardm_penalty_ref(model, seq_len, batch_size, order, uniforms, penalty, trace=None, start=None):
+    """generate.py:180-215 with the repetition penalty (:202-210).  ``uniforms`` (2 * n_steps, B): row s feeds the
+    batched draw of step s, row n_steps + s entry j the re-draw of sequence j at that step.  A re-draw happens when the
+    drawn token equals the token already sitting left or right of the position (the ends have one neighbour); the drawn
+    token's probability is divided by ``penalty`` (the row is NOT renormalised: the inverse CDF, like
+    torch.multinomial, works on unnormalised weights) and the sequence draws once more."""
+    sample = torch.full((batch_size, seq_len), MASK_ID, dtype=torch.long) if start is None else start.clone()
+    n_steps = len(order)
+    timestep = torch.zeros(batch_size, dtype=torch.long)
+    for s, i in enumerate(int(v) for v in order):
+        p = F.softmax(model(sample, timestep)[:, i, :OADM_DRAW], dim=1)
+        tok, margin = inverse_cdf(p, uniforms[s])
+        redrawn = []
+        for j in range(batch_size):
+            near = [sample[j, k] for k in (i - 1, i + 1) if 0 <= k < seq_len]
+            if any(int(t) == int(tok[j]) for t in near):
+                p[j, int(tok[j])] /= penalty
+                t2, m2 = inverse_cdf(p[j].unsqueeze(0), uniforms[n_steps + s, j].reshape(1))
+                tok[j], margin[j] = t2[0], torch.minimum(margin[j], m2[0])
+                redrawn.append(j)
+        sample[:, i] = tok
+        if trace is not None:
+            trace.append(dict(pos=i, redrawn=redrawn, margin=margin.clone(), tok=tok.clone()))
+    return sample
+
+
+@torch.no_grad()
+def generate_autoreg_scaffold_ref(model, sample_ref, start_id: int, stop_id: int, mask_id: int, n_alphabet: int,
+                                  uniforms, trace=None):
+    """conditional_generation.py:537-574 for one sequence.  ``sample_ref`` (L,): the scaffold with the motif in place
+    and ``mask_id`` elsewhere; ``uniforms`` (L,): the draw at output position i uses entry i.  The sequence grows from
+    START; a run of given tokens that starts at i is appended whole; other positions are drawn from the prefix, over
+    the first ``stop_id`` logits until i is past the last given position and over all ``n_alphabet`` after that, where
+    STOP ends the loop.  Returns the tokens without START and without the last one (:573-574)."""
+    L = int(sample_ref.shape[0])
+    given = (sample_ref != mask_id)
+    last_given = int(given.nonzero().max())
+    sample = torch.full((1, 1), start_id, dtype=torch.long)
+    timestep = torch.zeros(1, dtype=torch.long)
+    i = 0
+    while i < L:
+        if given[i]:
+            j = i
+            while j < L and given[j]:
+                j += 1
+            sample = torch.cat((sample, sample_ref[i:j].reshape(1, -1)), dim=1)
+            i = j
+            continue
+        n = n_alphabet if i > last_given else stop_id
+        p = torch.softmax(model(sample, timestep)[:, -1, :n], dim=1)
+        tok, margin = inverse_cdf(p, uniforms[i].reshape(1))
+        sample = torch.cat((sample, tok.reshape(1, 1)), dim=1)
+        if trace is not None:
+            trace.append({"i": i, "p": p[0].clone(), "tok": int(tok), "margin": float(margin)})
+        i += 1
+        if int(tok) == stop_id:
+            break
+    return sample[0, 1:-1]
+
+
 def d3pm_posterior(p: torch.Tensor, x_t: torch.Tensor, Q_t: torch.Tensor, Qbar_tm1: torch.Tensor):
     """generate.py:284-290 for a whole batch: p (B, L, K) fp64 softmax, x_t (B, L) tokens.
 

@@ -80,6 +80,30 @@ def test_bench_self_launch_and_world_size_independent_tokens():
     assert weak1["tokens_sha256"] == weak2["tokens_sha256"]
 
 
+def test_config4_strong_scaling_form_at_world_two():
+    """BASELINE config 4's own flags (`--total-sequences ... --seq-len 512`, sub-batches of 64) through bench.py's
+    launcher at world 1 and 2, with a sequence count that leaves the two shards uneven and not a multiple of the
+    sub-batch (4095 -> 2048 + 2047): one line, n_gpus / rccl_ranks from the process group, equal tokens."""
+    flags = ["--steps", "1", "--warmup", "0", "--total-sequences", "4095", "--seq-len", "512", "--batch", "64"]
+    one = _bench_line("--gpus", "1", *flags)
+    two = _bench_line("--gpus", "2", *flags)
+    assert (one["n_gpus"], one["rccl_ranks"]) == (1, 1) and (two["n_gpus"], two["rccl_ranks"]) == (2, 2)
+    assert one["config"]["global_batch"] == two["config"]["global_batch"] == 4095 and two["scaling"] == "strong"
+    assert one["tokens_sha256"] == two["tokens_sha256"]
+
+
+def test_bench_refuses_a_rank_without_a_gpu():
+    """`--gpus N` on a node with fewer GPUs must fail loudly on the rank that has none, before any collective: here (no
+    GPU at all) already rank 0 of a one-rank job says so."""
+    import subprocess
+    if torch.cuda.device_count() > 0:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode != 0 and "sees 0 GPU(s)" in run.stderr
+
+
 def test_global_sub_batch_grid_and_streams():
     sys.path.insert(0, ROOT)
     from evodiff_amd.parallel import batch_order, global_sub_batches, sequence_uniforms, shard_range

@@ -580,13 +580,127 @@ def test_conditional_callers_against_oracle(dev):
     start[:, new_start:new_start + len(motif)] = torch.tensor(tok.tokenize((motif,)))
     trace = []
     ref = R.generate_oaardm_ref(oracle, L, 2, order, uni, trace=trace, start=start)
-    strings, starts, ends = generate_scaffold(m, motif, scaffold_length, tok, batch_size=2, device=dev,
-                                              new_start=new_start, order=order, uniforms=uni)
+    strings, starts, ends = generate_scaffold(m, "1abc", [0], [len(motif) - 1], scaffold_length, "/nowhere/", tok,
+                                              batch_size=2, device=dev, motif_seq=motif, new_start=new_start,
+                                              order=order, uniforms=uni)
     assert (starts, ends) == ([new_start], [new_start + len(motif) - 1])
     assert all(s[new_start:new_start + len(motif)] == motif and "#" not in s for s in strings)
     assert min(float(t["margin"].min()) for t in trace) > DRAW_MARGIN_FP32, "seed gives a boundary-ambiguous draw"
     assert strings == [tok.untokenize(r) for r in ref]
     assert get_intervals([3, 4, 5, 9, 10, 20, 21]) == ([3, 9, 20], [5, 10, 21])
+
+
+def _sharp_oracle(cfg, seed, scale):
+    oracle = R.build_model(cfg, None, seed)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(scale))
+    return oracle
+
+
+def test_repetition_penalty_against_reference_trace(golden_dir, dev):
+    """generate_oaardm(penalty=...) (generate.py:202-210): the fixture is the reference's own loop run verbatim with
+    pre-drawn uniforms (oracle/make_golden_r3.py; 50 re-draws in 160 draws); every draw's margin there is beyond
+    DRAW_MARGIN_FP32, so the fp32 path must reproduce the final tokens and strings exactly."""
+    from evodiff_amd.generate import generate_oaardm
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(golden_dir, "oadm_penalty_trace.npz"))
+    assert min(float(g["first_margin"].min()), float(g["redraw_margin"].min())) > DRAW_MARGIN_FP32
+    m = product_model(_sharp_oracle(TINY_WIDE, 12, g["decoder_scale"]), TINY_WIDE, precision="fp32")
+    B, L = g["final"].shape
+    sample, strings = generate_oaardm(m, Tokenizer(), L, penalty=float(g["penalty"]), batch_size=B, device=dev,
+                                      order=g["order"], uniforms=torch.from_numpy(g["uniforms"]))
+    assert np.array_equal(sample.cpu().numpy(), g["final"])
+    assert strings == [str(x) for x in g["strings"]]
+    # and without the penalty the same uniforms give other sequences (the branch really ran)
+    plain, _ = generate_oaardm(m, Tokenizer(), L, batch_size=B, device=dev, order=g["order"],
+                               uniforms=torch.from_numpy(g["uniforms"][:L]))
+    assert not np.array_equal(plain.cpu().numpy(), g["final"])
+
+
+def test_inpaint_and_scaffold_against_reference_trace(golden_dir, dev):
+    """inpaint (two sequences of different length, conditional_generation.py:628-675) and generate_scaffold with the
+    reference's positional signature (:475-476; a two-segment motif, batch 2) against the reference's own loops run
+    verbatim (oracle/make_golden_r3.py), fp32, every margin beyond DRAW_MARGIN_FP32."""
+    from evodiff_amd.conditional_generation import generate_scaffold, inpaint
+    from evodiff_amd.utils import Tokenizer
+    g = np.load(os.path.join(golden_dir, "conditional_trace.npz"))
+    assert min(float(g["inpaint_margin"].min()), float(g["scaffold_margin"].min())) > DRAW_MARGIN_FP32
+    m = product_model(_sharp_oracle(TINY_WIDE, 12, g["decoder_scale"]), TINY_WIDE, precision="fp32")
+    tok = Tokenizer()
+    seqs = [str(x) for x in g["inpaint_seqs"]]
+    starts, ends = g["inpaint_starts"].tolist(), g["inpaint_ends"].tolist()
+    tokenized = [torch.tensor(tok.tokenizeMSA(x)) for x in seqs]
+    res = inpaint(m, tokenized, starts, ends, seqs, tokenizer=tok, device=dev,
+                  orders=[g["inpaint_order0"], g["inpaint_order1"]],
+                  uniforms=[torch.from_numpy(g["inpaint_uni0"]), torch.from_numpy(g["inpaint_uni1"])])
+    assert [x[0] for x in res[0]] == [str(x) for x in g["inpaint_out_seqs"]]
+    assert res[1] == [[x] for x in seqs]
+    assert res[2] == [str(x) for x in g["inpaint_out_idrs"]] and res[3] == [str(x) for x in g["inpaint_ref_idrs"]]
+    assert (res[4], res[5]) == (starts, ends)
+    # generate_scaffold, called exactly as the reference is (PDB id, motif segment indices, data directory): the motif
+    # string stands in for the PDB file
+    strings, s_idx, e_idx = generate_scaffold(m, "XXXX", [0, 7], [4, 9], int(g["scaffold_length"]), "/nowhere/", tok,
+                                              batch_size=2, device=dev, motif_seq=str(g["scaffold_motif"]),
+                                              new_start=int(g["scaffold_new_start"]), order=g["scaffold_order"],
+                                              uniforms=torch.from_numpy(g["scaffold_uni"]))
+    assert strings == [str(x) for x in g["scaffold_strings"]]
+    assert (s_idx, e_idx) == (g["scaffold_start_idxs"].tolist(), g["scaffold_end_idxs"].tolist())
+    with pytest.raises(FileNotFoundError, match="does not download"):
+        generate_scaffold(m, "XXXX", [0, 7], [4, 9], 30, "/nowhere/", tok, batch_size=1, device=dev)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_autoreg_scaffold_against_reference_trace(golden_dir, dev, precision):
+    """generate_autoreg_scaffold (conditional_generation.py:515-576) on ed_ar_sample_scaffold: motif segments spliced
+    into the growing sequence, draws over [:stop_id] up to the last motif residue and over the whole alphabet after it,
+    cut at STOP.  fp32: the strings of the reference's own loop (run verbatim on the oracle's causal block; margins beyond
+    DRAW_MARGIN_FP32).  bf16: per draw against the oracle wherever its margin allows, up to the first draw that does
+    not."""
+    from evodiff_amd.conditional_generation import generate_autoreg_scaffold
+    from evodiff_amd.utils import Tokenizer
+    from evodiff_amd.constants import ALL_AAS, PAD, PROTEIN_ALPHABET
+    g = np.load(os.path.join(golden_dir, "conditional_trace.npz"))
+    alphabet = str(g["ar_alphabet"])
+    assert alphabet == PROTEIN_ALPHABET
+    cfg = dict(TINY_WIDE, n_tokens=30, causal=True)
+    oracle = R.build_model(cfg, None, int(g["ar_seed"]))
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+        oracle.decoder.conv.bias[alphabet.index("*")] += float(g["ar_stop_bias"])
+    m = product_model(oracle, cfg, precision=precision)
+    tok = Tokenizer(protein_alphabet=PROTEIN_ALPHABET, all_aas=ALL_AAS, pad=PAD)
+    motif, n_sc = str(g["ar_motif"]), int(g["ar_scaffold_length"])
+    exact = 0
+    for r in range(len(g["ar_new_start"])):
+        uni = torch.from_numpy(g["ar_uni"][r]).reshape(-1, 1)
+        strings, s_idx, e_idx = generate_autoreg_scaffold(m, "XXXX", [0, 4], [2, 6], n_sc, "/nowhere/", tok, batch_size=1,
+                                                          device=dev, motif_seq=motif, new_start=int(g["ar_new_start"][r]),
+                                                          uniforms=uni)
+        assert (s_idx, e_idx) == (g[f"ar{r}_start_idxs"].tolist(), g[f"ar{r}_end_idxs"].tolist())
+        want = str(g["ar_strings"][r])
+        margin = g[f"ar{r}_margin"]
+        tol = DRAW_MARGIN_FP32 if precision == "fp32" else DRAW_MARGIN_BF16
+        if margin.min() > tol:
+            assert strings[0] == want, r
+            exact += 1
+        else:                       # comparable up to the first boundary-ambiguous draw: its output position
+            ns = int(g["ar_new_start"][r])
+            given = np.zeros(n_sc + len(motif), bool)
+            given[ns:ns + len(motif)] = np.array(list(motif)) != "#"
+            drawn_pos = np.flatnonzero(~given)[: len(margin)]
+            first_bad = int(drawn_pos[np.argmax(margin <= tol)])
+            assert strings[0][:first_bad] == want[:first_bad], r
+    if precision == "fp32":
+        assert exact == len(g["ar_new_start"])
+    # a batch of scaffolds around one placement: row b equals the single-sequence call with the same uniforms
+    uni = torch.from_numpy(np.random.default_rng(3).random((n_sc + len(motif), 3), dtype=np.float32))
+    many, _, _ = generate_autoreg_scaffold(m, "XXXX", [0, 4], [2, 6], n_sc, "/nowhere/", tok, batch_size=3, device=dev,
+                                           motif_seq=motif, new_start=5, uniforms=uni)
+    one, _, _ = generate_autoreg_scaffold(m, "XXXX", [0, 4], [2, 6], n_sc, "/nowhere/", tok, batch_size=1, device=dev,
+                                          motif_seq=motif, new_start=5, uniforms=uni[:, 1:2].contiguous())
+    assert all(s[5:8] == "WKL" and s[9:12] == "PEN" for s in many if len(s) >= 12)
+    if precision == "fp32":         # (in bf16 the K-loop cut of the small problems depends on the batch size)
+        assert many[1] == one[0]
 
 
 def test_errors_are_raised_not_faults(dev):
@@ -865,6 +979,52 @@ def test_flagship_geometry_free_running_bf16_trajectory_against_oracle(dev):
         idx, margin = R.inverse_cdf(torch.softmax(logits, dim=-1), uni[s, rows])
         n_safe += _check_draws(final[rows, int(order[s])].numpy(), idx.numpy(), margin.numpy(), DRAW_MARGIN_BF16)
     assert n_safe > 0.5 * n * len(rows), "test is vacuous: most draws sit on a category boundary"
+
+
+def test_benchmark_configuration_pinned_to_the_oracle(dev):
+    """BASELINE config 2 exactly as bench.py runs it - the real 56-layer OA_DM_640M(random_init=True) under seed 0 with
+    bench.py's decoder sharpening, B = 64, L = 256, bf16, DEFAULT execution options (LayerNorms in the epilogues, pruned
+    trailing layers, incremental leading layers with the cached LayerNorm 1), graph replay, bench.py's own seeding of the
+    order and the uniforms - held to the oracle directly (VERDICT r02 weak point 1):
+    (a) ``model(x)`` on a half-filled batch of 64: the logits of three of its rows within BF16_TOL;
+    (b) the whole free-running 256-step loop, then three rows x 16 steps spread over the loop (the cache-filling step,
+        incremental steps, early / middle / late positions) teacher-forced through the oracle (oracle/spot_check.py): every
+        draw outside DRAW_MARGIN_BF16 of a category boundary is the oracle's."""
+    import bench
+    from evodiff_amd.parallel import batch_order, sequence_uniforms
+    from evodiff_amd.pretrained import OA_DM_640M
+    from oracle.spot_check import oadm_spot_check, spread_steps
+    B, L = 64, 256
+    torch.manual_seed(0)
+    m, _, tok, _ = OA_DM_640M(random_init=True)
+    bench.sharpen_decoder(m, bench.DECODER_SCALE)
+    m.precision, m.use_graph = "bf16", True
+    oracle = R.build_model(R.MODEL_CONFIGS["640M"], None, None)
+    oracle.load_state_dict(m.state_dict())
+    order = batch_order(bench.SEED_ORDER, 0, L)
+    uni = torch.from_numpy(sequence_uniforms(bench.SEED_UNIFORM, 0, B, (L,)))
+    rows = [0, 31, 63]
+    # (a) forward
+    rng = np.random.default_rng(4)
+    x = torch.full((B, L), R.MASK_ID, dtype=torch.long)
+    x[:, rng.permutation(L)[: L // 2]] = torch.from_numpy(rng.integers(0, 20, (B, L // 2)))
+    got = m(x.to(dev), torch.zeros(B, dtype=torch.long, device=dev))[rows].cpu().numpy()
+    with torch.no_grad():
+        want = oracle(x[rows], torch.zeros(len(rows), dtype=torch.long)).numpy()
+    assert rel_err(got, want) < BF16_TOL
+    # (b) the benchmarked loop itself
+    sample = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
+    m.oadm_sample(sample, torch.from_numpy(order), uni.to(dev), R.OADM_DRAW)
+    m.check_errors()
+    final = sample.cpu()
+    assert int((final == tok.mask_id).sum()) == 0 and int(final.max()) < R.OADM_DRAW
+    res = oadm_spot_check(oracle, final, order, uni, rows, spread_steps(L, 16), DRAW_MARGIN_BF16)
+    assert res["agree"] == res["draws"], res
+    assert res["draws"] >= 0.5 * (res["draws"] + res["near_boundary"]), f"vacuous: {res}"
+    # the same call is what bench.py times: equal seeds, equal tokens (its tokens_sha256 covers this batch)
+    again = torch.full((B, L), tok.mask_id, dtype=torch.long, device=dev)
+    m.oadm_sample(again, torch.from_numpy(order), uni.to(dev), R.OADM_DRAW)
+    assert torch.equal(again, sample)
 
 
 def test_flagship_geometry_d3pm_forward_against_oracle(dev):

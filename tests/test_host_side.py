@@ -124,13 +124,99 @@ def test_loaded_checkpoint_alphabet_self_check(tmp_path):
                                      for k, v in sd.items()}}, bad)
     with pytest.raises(ValueError, match=r"constants\.py.*MSA_ALPHABET"):
         pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(bad))
-    # a checkpoint with no zero row at all (padding_idx never used) is refused too
+    # a checkpoint with no zero row at all (e.g. fine-tuned without padding_idx) proves nothing about the alphabet: the
+    # reference loads any state dict (pretrained.py:43-52), so this loads too, with a warning - and is refused only on
+    # request
     emb = sd["embedder.embedder.weight"].clone()
     emb[28] = 0.5
     torch.save({"model_state_dict": {"module." + k: (emb if k == "embedder.embedder.weight" else v)
                                      for k, v in sd.items()}}, bad)
-    with pytest.raises(ValueError, match="mask_id is 28"):
+    with pytest.warns(UserWarning, match="mask_id is 28"):
         pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(bad))
+    os.environ["EVODIFF_AMD_STRICT_ALPHABET"] = "1"
+    try:
+        with pytest.raises(ValueError, match="mask_id is 28"):
+            pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(bad))
+    finally:
+        del os.environ["EVODIFF_AMD_STRICT_ALPHABET"]
+    # a second zero row besides the mask row: a warning as well
+    emb = sd["embedder.embedder.weight"].clone()
+    emb[30] = 0.0
+    torch.save({"model_state_dict": {"module." + k: (emb if k == "embedder.embedder.weight" else v)
+                                     for k, v in sd.items()}}, bad)
+    with pytest.warns(UserWarning, match=r"\[28, 30\]"):
+        pretrained.load_sequence_checkpoint("oaar-38M", cfg, None, path_to_checkpoints=str(bad))
+
+
+@pytest.mark.parametrize("nested", [False, True])
+def test_causal_checkpoint_key_layouts(tmp_path, nested):
+    """LR-AR checkpoints (pretrained.py:48-49: keys without the DDP prefix).  Whether sequence_models'
+    MaskedCausalConv1d is a Conv1d (``layers.i.conv.weight``) or wraps one (``layers.i.conv.conv.weight``) cannot be
+    checked offline, so a causal checkpoint loads in either layout; a non-causal one stays strict."""
+    from evodiff_amd import pretrained
+    from evodiff_amd.constants import ALL_AAS, PAD, PROTEIN_ALPHABET
+    from evodiff_amd.utils import Tokenizer
+    cfg = os.path.join(ROOT, "evodiff_amd", "config", "config38M.json")
+    tok = Tokenizer(protein_alphabet=PROTEIN_ALPHABET, all_aas=ALL_AAS, pad=PAD)
+    torch.manual_seed(8)
+    src, _ = pretrained.load_sequence_checkpoint("lrar-38M", cfg, None, tokenizer=tok, causal=True, n_tokens=30, random_init=True)
+    rename = (lambda k: re.sub(r"(layers\.\d+\.conv)\.(weight|bias)$", r"\1.conv.\2", k)) if nested else (lambda k: k)
+    sd = {rename(k): v for k, v in src.state_dict().items()}
+    assert ("embedder.layers.3.conv.conv.weight" in sd) == nested and "embedder.layers.3.sequence1.2.conv.weight" in sd
+    path = tmp_path / "lrar-38M.tar"
+    torch.save({"model_state_dict": sd}, path)
+    dst, _ = pretrained.load_sequence_checkpoint("lrar-38M", cfg, None, tokenizer=tok, causal=True, n_tokens=30,
+                                                 path_to_checkpoints=str(path))
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+    model, _, tok2, scheme = pretrained.LR_AR_38M(path_to_checkpoints=str(path))
+    assert scheme == "causal-mask" and model.hparams["causal"] == 1 and tok2.stop_id == 26
+    if nested:       # the nested layout is a causal-model thing only
+        with pytest.raises(RuntimeError, match="conv.conv"):
+            pretrained.load_sequence_checkpoint("carp-38M", cfg, None, tokenizer=tok, causal=False, n_tokens=30,
+                                                path_to_checkpoints=str(path))
+
+
+def test_conditional_callers_bind_like_the_reference(tmp_path):
+    """A caller written against evodiff/conditional_generation.py binds unchanged: same positional parameters, in the
+    same order, with the same defaults (:475-476, :515-516, :603, :628-629); extras are keyword-only.  get_motif reads
+    a PDB file that is already on disk (chain selection, '#' spacers between segments, inclusive end indices, :418-453)
+    and never downloads."""
+    import inspect
+    from evodiff_amd import conditional_generation as cg
+    want = {
+        "generate_scaffold": ["model", "PDB_ID", "motif_start_idxs", "motif_end_idxs", "scaffold_length", "data_top_dir",
+                              "tokenizer", "batch_size", "device", "random_baseline", "single_res_domain", "chain"],
+        "generate_autoreg_scaffold": ["model", "PDB_ID", "motif_start_idxs", "motif_end_idxs", "scaffold_length",
+                                      "data_top_dir", "tokenizer", "batch_size", "device", "single_res_domain", "chain"],
+        "inpaint_simple": ["model", "sequence", "start_idx", "end_idx", "tokenizer", "device"],
+        "inpaint": ["model", "tokenized_sequences", "start_idxs", "end_idxs", "sequences", "tokenizer", "device",
+                    "random_baseline", "data_top_dir"],
+        "get_motif": ["PDB_ID", "start_idxs", "end_idxs", "data_top_dir", "chain"],
+    }
+    for name, params in want.items():
+        sig = inspect.signature(getattr(cg, name))
+        positional = [p.name for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+        assert positional == params, name
+    sig = inspect.signature(cg.generate_scaffold)
+    assert sig.parameters["device"].default == "gpu" and sig.parameters["chain"].default == "A"
+    # a small two-chain PDB file on disk
+    residues = {"A": ["GLU", "THR", "PHE", "SER", "ASP", "LEU", "TRP", "LYS"], "B": ["GLY", "ALA"]}
+    lines, serial = [], 1
+    for chain, names in residues.items():
+        for n, res in enumerate(names):
+            for atom in ("N", "CA", "C"):
+                lines.append("ATOM  %5d  %-3s %3s %s%4d    %8.3f%8.3f%8.3f  1.00 20.00           %s" %
+                             (serial, atom, res, chain, 25 + n, 1.0 * serial, 2.0, 3.0, atom[0]))
+                serial += 1
+    os.makedirs(tmp_path / "scaffolding-pdbs")
+    (tmp_path / "scaffolding-pdbs" / "9xyz.pdb").write_text("\n".join(lines) + "\nEND\n")
+    assert cg.read_pdb_sequence(str(tmp_path / "scaffolding-pdbs" / "9xyz.pdb"), "A") == "ETFSDLWK"
+    assert cg.get_motif("9xyz", [1], [3], data_top_dir=str(tmp_path)) == "TFS"
+    assert cg.get_motif("9xyz", [0, 5], [1, 7], data_top_dir=str(tmp_path)) == "ET###LWK"
+    assert cg.get_motif("9xyz", [0], [1], data_top_dir=str(tmp_path), chain="B") == "GA"
+    with pytest.raises(FileNotFoundError, match="does not download"):
+        cg.get_motif("1abc", [0], [1], data_top_dir=str(tmp_path))
 
 
 def test_ed_config_layout_agrees_everywhere():
@@ -322,3 +408,15 @@ def test_bench_flop_count_matches_survey_8d():
         assert abs(got - mflop_per_token) / mflop_per_token < 1e-3, (L, got, mflop_per_token)
     line = json.load(open(os.path.join(root, "profiles", "r01_bench.json")))
     assert abs(line["step_roofline"]["flops_per_sequence"] - bench.f_eff_per_sequence(big, 256) * 256) < 1e6
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/examples/scaffolding-pdbs"),
+                    reason="the reference's example PDB files only exist in the build container")
+@pytest.mark.parametrize("pdb_id,chain", [("1prw", "A"), ("1ycr", "B"), ("1bcf", "A"), ("5tpn", "A")])
+def test_pdb_sequence_reader_against_the_reference_fasta_files(pdb_id, chain):
+    """get_motif's sequence extraction (conditional_generation.py:428-433) on the reference's own cleaned PDB files:
+    the .fasta next to each of them is what its biotite-based reader wrote."""
+    from evodiff_amd.conditional_generation import read_pdb_sequence
+    d = "/root/reference/examples/scaffolding-pdbs/"
+    want = open(d + pdb_id + ".fasta").read().split("\n")[1].split(">")[0]
+    assert read_pdb_sequence(d + pdb_id + "_clean.pdb", chain) == want

@@ -193,3 +193,70 @@ def test_scoring_losses_match_reference(golden_dir):
         src, ts, tgt = (torch.from_numpy(g[f"d3{i}_{k}"]) for k in ("src", "timestep", "tgt"))
         t_out, nll, tokens = R.sum_nll_ref(m, "d3pm", src, ts, tgt)
         assert tokens == src.shape[1] and abs(nll - float(g[f"d3{i}_nll"])) <= 1e-5 * abs(float(g[f"d3{i}_nll"]))
+
+
+def _sharp(cfg, seed, scale):
+    m = R.build_model(cfg, None, seed)
+    with torch.no_grad():
+        m.decoder.conv.weight.mul_(float(scale))
+    return m
+
+
+def test_repetition_penalty_loop_matches_reference(golden_dir):
+    """generate_oaardm(penalty=3) run verbatim (oracle/make_golden_r3.py): final tokens, every first draw and every
+    re-draw (which step, which sequence, which token) of the oracle's restatement are the reference's."""
+    g = load(golden_dir, "oadm_penalty_trace.npz")
+    m = _sharp(TINY_WIDE, 12, g["decoder_scale"])
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])
+    B, L = g["final"].shape
+    trace = []
+    out = R.generate_oaardm_penalty_ref(m, L, B, g["order"], torch.from_numpy(g["uniforms"]), float(g["penalty"]), trace=trace)
+    assert np.array_equal(out.numpy(), g["final"])
+    redraws = [(s, j) for s, t in enumerate(trace) for j in t["redrawn"]]
+    assert redraws == list(zip(g["redraw_step"].tolist(), g["redraw_seq"].tolist())) and len(redraws) >= 5
+    tok = R.Tokenizer()
+    assert [tok.untokenize(r) for r in out] == [str(s) for s in g["strings"]]
+
+
+def test_conditional_callers_match_reference(golden_dir):
+    """inpaint / generate_scaffold / generate_autoreg_scaffold run verbatim (oracle/make_golden_r3.py) against the
+    oracle's loops on the same start, order and uniforms."""
+    g = load(golden_dir, "conditional_trace.npz")
+    m = _sharp(TINY_WIDE, 12, g["decoder_scale"])
+    assert sd_digest(m.state_dict()) == str(g["sd_sha"])
+    tok = R.Tokenizer()
+    enc = lambda s: torch.tensor([tok.a_to_i[a] for a in s])
+    for s in range(2):                      # inpaint: the region is re-sampled from the unmasked sequence around it
+        seq, a, b = str(g["inpaint_seqs"][s]), int(g["inpaint_starts"][s]), int(g["inpaint_ends"][s])
+        out = R.generate_oaardm_ref(m, len(seq), 1, g[f"inpaint_order{s}"], torch.from_numpy(g[f"inpaint_uni{s}"]),
+                                    start=enc(seq).unsqueeze(0))
+        assert tok.untokenize(out[0]) == str(g["inpaint_out_seqs"][s])
+        assert tok.untokenize(out[0, a:b]) == str(g["inpaint_out_idrs"][s]) and seq[a:b] == str(g["inpaint_ref_idrs"][s])
+    motif, ns, n_sc = str(g["scaffold_motif"]), int(g["scaffold_new_start"]), int(g["scaffold_length"])
+    L = n_sc + len(motif)
+    start = torch.full((2, L), R.MASK_ID, dtype=torch.long)
+    start[:, ns:ns + len(motif)] = enc(motif)
+    out = R.generate_oaardm_ref(m, L, 2, g["scaffold_order"], torch.from_numpy(g["scaffold_uni"]), start=start)
+    assert [tok.untokenize(r) for r in out] == [str(s) for s in g["scaffold_strings"]]
+    # causal model over the 30-token alphabet
+    alphabet = str(g["ar_alphabet"])
+    mc = R.build_model(dict(TINY_WIDE, n_tokens=30, causal=True), None, int(g["ar_seed"]))
+    with torch.no_grad():
+        mc.decoder.conv.weight.mul_(float(g["decoder_scale"]))
+        mc.decoder.conv.bias[alphabet.index("*")] += float(g["ar_stop_bias"])
+    assert sd_digest(mc.state_dict()) == str(g["ar_sd_sha"])
+    motif, n_sc = str(g["ar_motif"]), int(g["ar_scaffold_length"])
+    L = n_sc + len(motif)
+    lengths = set()
+    for r in range(len(g["ar_new_start"])):
+        ns = int(g["ar_new_start"][r])
+        ref = torch.full((L,), alphabet.index("#"), dtype=torch.long)
+        ref[ns:ns + len(motif)] = torch.tensor([alphabet.index(a) for a in motif])
+        trace = []
+        out = R.generate_autoreg_scaffold_ref(mc, ref, alphabet.index("@"), alphabet.index("*"), alphabet.index("#"),
+                                              len(alphabet), torch.from_numpy(g["ar_uni"][r]), trace=trace)
+        assert "".join(alphabet[int(t)] for t in out) == str(g["ar_strings"][r])
+        assert len(trace) == int(g["ar_n_draws"][r])
+        assert [len(t["p"]) for t in trace] == g[f"ar{r}_n_classes"].tolist()
+        lengths.add(len(out))
+    assert len(lengths) > 1                 # some runs end at STOP, early
