@@ -1281,6 +1281,9 @@ int ed_debug_gemm(const void* A_dev, int64_t a_seq_pitch, int64_t a_row0, const 
   if (kernel >= 3 && kernel < 100) {  // diagnostic ablations of the tuned kernel (3: no MFMAs, 4: no DMA); results are not valid
     p.ablate = kernel - 2;
     kernel = 2;
+    // the no-MFMA / no-copy forms exist with fp32 stores and no residual only: a bf16 output buffer is half as large
+    if ((p.ablate == 1 || p.ablate == 2) && (out_bf16 || resid_dev))
+      return fail(ED_EINVAL, "kernels 3 and 4 (ablated forms) store fp32 and take no residual: pass out_bf16 = 0, resid = NULL");
     if (p.ablate == 7) {  // in-kernel clock stamps: eight values per 256-row tile
       const int64_t tiles = (int64_t)B * ((L + 255) / 256) * ((N + 255) / 256);
       if (!g_stamp_buf || g_stamp_cap < 8 * tiles) return fail(ED_EINVAL, "stamp buffer missing or too small");

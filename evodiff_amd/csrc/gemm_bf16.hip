@@ -65,6 +65,7 @@ hipError_t launch_nt(const GemmProblem& p, hipStream_t stream) {
   }
 #define ED_GO(OB, RS, AB) \
   hipLaunchKernelGGL((gemm_bf16_kernel<NT, CONV, OB, RS, AB, 0, WM>), grid, block, 0, stream, p, tiles_n, tiles_total)
+  if ((p.ablate == 1 || p.ablate == 2) && (p.out_bf16 || p.resid)) return hipErrorInvalidValue;  // (fp32 stores only)
   if (p.ablate == 1) ED_GO(false, false, 1);
   else if (p.ablate == 2) ED_GO(false, false, 2);
   else if (p.ablate == 7 && p.stamps) {
