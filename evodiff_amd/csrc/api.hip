@@ -121,6 +121,10 @@ struct ed_model {
   std::vector<DevBuf> Car;
   int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf ar_keep, ar_ndraw;   // ed_ar_sample_scaffold: given positions (L bytes), classes per step (n_steps ints)
+  int ar_gemv = 4;            // ED_OPT_AR_GEMV: autoregressive batches up to this many sequences take the weight-streaming
+                              // kernels (ar_gemv.hip); 0 = never, at most AR_GEMV_MAX_B.  Measured per step, 640M: 1.14 / 1.62 /
+                              // 2.25 ms at B = 1 / 4 / 8 against 1.99 / 2.01 / 2.04 on the tile kernels
+  int n_cus = 0;              // compute units of the model's device
   bool ar_forced = false;     // the current autoregressive call uses them
   // LayerNorm fused into the tuned kernels' epilogues (ED_OPT_FUSE_LN, ln_epilogue.hpp): exchange buffer for the per-row
   // partial statistics, arrival counters (one array per GEMM of the block: a counter must always see the same number of
@@ -742,6 +746,16 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   void* Y = m->Ybuf.p;
   int rc;
   bool ln1_done = false;
+  // few sequences, bf16: three weight-streaming launches per block (ar_gemv.hip), each applying the LayerNorm in front of
+  // its GEMM itself; the raw GEMM results stay fp32 between them
+  const bool gemv = h && B <= m->ar_gemv && c.kernel_size == 5;
+  auto run_gemv = [&](const ArGemv& g, int kind) -> int {
+    Probe pr(m, s);
+    LAUNCH_TRY(pr.begin());
+    LAUNCH_TRY(launch_ar_gemv(g, m->n_cus, s));
+    LAUNCH_TRY(pr.end(kind, 2.0 * g.B * g.N * (double)g.C * g.ntaps, (double)g.ntaps * g.N * g.C * 2.0));
+    return ED_OK;
+  };
   {
     Probe pr(m, s);
     LAUNCH_TRY(pr.begin());
@@ -751,6 +765,18 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   }
   for (int k = 0; k < c.n_layers; ++k) {
     const LayerW& w = m->layers[k];
+    if (gemv) {
+      float* y1 = (float*)Y;
+      float* y2 = (float*)A;
+      ArGemv g1{x, D, w.ln1_g, w.ln1_b, D, act, w.w1_h, w.b1, nullptr, y1, B, H, 1, 1, nullptr, 0, 0, PosBit{}};
+      ArGemv gc{y1, H, w.ln2_g, w.ln2_b, H, act, w.wc_h, w.bc, nullptr, y2, B, H, c.kernel_size, w.dilation,
+                m->Car[k].as<bf16_t>(), m->conv_pitch, m->conv_row0, pos};
+      ArGemv g2{y2, H, w.ln3_g, w.ln3_b, H, act, w.w2_h, w.b2, x, x, B, D, 1, 1, nullptr, 0, 0, PosBit{}};
+      if (!ar_gemv_supported(g1) || !ar_gemv_supported(gc) || !ar_gemv_supported(g2))
+        return fail(ED_ESTATE, "autoregressive weight-streaming path: unsupported geometry (set ED_OPT_AR_GEMV = 0)");
+      if ((rc = run_gemv(g1, ED_K_GEMM1X1)) || (rc = run_gemv(gc, ED_K_CONV_OTHER)) || (rc = run_gemv(g2, ED_K_GEMM1X1))) return rc;
+      continue;
+    }
     if (!ln1_done && (rc = run_ln(m, x, false, A, h, w.ln1_g, w.ln1_b, B, D, LnRowMap::plain(B), act, s))) return rc;
     ln1_done = false;
     GemmProblem g1{A, B, 0, h ? (const void*)w.w1_h : (const void*)w.w1_f, w.b1, Y, nullptr, 1, B, H, D, 1, 1, h, h};
@@ -908,6 +934,7 @@ int ed_model_create(const ed_config* cfg, int device, ed_model** out) {
   if (!m) return fail(ED_ENOMEM, "out of host memory");
   m->cfg = c;
   m->device = device;
+  (void)hipDeviceGetAttribute(&m->n_cus, hipDeviceAttributeMultiprocessorCount, device);
   hipError_t e = hipHostMalloc((void**)&m->ln_err_host, ED_AERR_WORDS * sizeof(unsigned), hipHostMallocMapped);
   if (e == hipSuccess) {
     std::memset(m->ln_err_host, 0, ED_AERR_WORDS * sizeof(unsigned));
@@ -1475,6 +1502,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_FUSE_LN:
       if (value != 0 && value != 1) return fail(ED_EINVAL, "ED_OPT_FUSE_LN takes 0 or 1");
       m->fuse_ln = value != 0;
+      break;
+    case ED_OPT_AR_GEMV:
+      if (value < 0 || value > AR_GEMV_MAX_B) return fail(ED_EINVAL, "ED_OPT_AR_GEMV must be in [0, 8]");
+      m->ar_gemv = value;
       break;
     case ED_OPT_SPLIT_MIN_ITERS:
       if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");

@@ -221,6 +221,28 @@ hipError_t launch_final_d3pm(const float* X, const float* gamma, const float* be
 
 hipError_t launch_advance_step(StepState* state, hipStream_t stream);
 
+// Weight-streaming GEMM on a few rows (ar_gemv.hip): out[b][n] = bias[n] (+ resid[b][n]) + sum_{t, k} W[t][n][k] * a[b][t][k]
+// for b < B <= AR_GEMV_MAX_B, where a[b][ntaps-1] = act(LayerNorm(in[b])) * gamma + beta rounded to bf16 (the LayerNorm in
+// front of the GEMM, applied by the consumer) and, for the causal convolution (ntaps = 5), a[b][t] for t < ntaps-1 are
+// the rows pos - (ntaps-1-t) * dilation of the layer's cache of such rows, to which the new row is appended at pos.
+constexpr int AR_GEMV_MAX_B = 8;
+struct ArGemv {
+  const float* in;       // [B] rows of C fp32 values, in_pitch elements apart: the raw input of the LayerNorm
+  long in_pitch;
+  const float *gamma, *beta;  // [C]
+  int C, act;            // act: 0 none, 1 GELU (the bf16 path's fit), 2 ReLU
+  const bf16_t* W;       // [ntaps][N][C]
+  const float* bias;     // [N]
+  const float* resid;    // nullptr, or fp32 [B][N] (may alias out: an element is read and written by the same lane)
+  float* out;            // fp32 [B][N]
+  int B, N, ntaps, dilation;
+  bf16_t* cache;         // ntaps > 1: [B][cache_pitch][C] bf16, position 0 at row cache_row0 (zero rows in front)
+  long cache_pitch, cache_row0;
+  PosBit pos;            // position of the new row
+};
+bool ar_gemv_supported(const ArGemv& p);
+hipError_t launch_ar_gemv(const ArGemv& p, int n_cus, hipStream_t stream);
+
 // Asynchronous error words (host-visible memory, one 4-byte word per code): kernels raise them instead of the host
 // validating device data with a copy and a synchronisation per call; the C ABI reports them on the next call.
 enum { ED_AERR_LN_WAIT = 0, ED_AERR_TOKEN = 1, ED_AERR_TIMESTEP = 2, ED_AERR_ORDER = 3, ED_AERR_TARGET = 4, ED_AERR_WORDS = 16 };

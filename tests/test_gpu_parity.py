@@ -981,6 +981,52 @@ def test_flagship_geometry_free_running_bf16_trajectory_against_oracle(dev):
     assert n_safe > 0.5 * n * len(rows), "test is vacuous: most draws sit on a category boundary"
 
 
+@pytest.mark.parametrize("base,B", [(TINY_WIDE, 1), (TINY_WIDE, 5), (BIG640, 8), (MID, 3), (WIDE1280, 2)])
+def test_autoregressive_weight_streaming_kernels_against_oracle_and_tile_kernels(dev, base, B):
+    """ED_OPT_AR_GEMV (ar_gemv.hip; the option is the largest batch that takes them, 8 here so that every case does):
+    autoregressive steps of at most 8 sequences as three weight-streaming launches per block, each applying the LayerNorm in front of its GEMM itself.  Per-step probabilities against the oracle
+    (teacher-forced along the GPU's own sequences: one causal forward gives every step's distribution) and against the
+    tile-kernel path (same arithmetic up to the order of the fp32 sums and one bf16 rounding less); tokens are the
+    inverse-CDF draws from the GPU's own probabilities; graph replay equals eager launches bit for bit; 9 sequences take
+    the tile kernels whatever the option says.  Shapes: 256 / 640 / 1280 wide, slim (d_hidden = d_model / 2 = 192)."""
+    cfg = dict(base, n_tokens=30, causal=True, n_layers=min(base["n_layers"], 9))
+    oracle = R.build_model(cfg, None, 57)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(4.0)
+    m = product_model(oracle, cfg, precision="bf16")
+    n = 40
+    uni = torch.from_numpy(np.random.default_rng(B).random((n, B), dtype=np.float32)).to(dev)
+
+    def run(gemv, use_graph=True, rows=B, u=uni):
+        m.set_option("ar_gemv", gemv)
+        m.use_graph = use_graph
+        sample = torch.full((rows, n + 1), 29, dtype=torch.long, device=dev)
+        probs = m.ar_sample(sample, u, n_steps=n, return_probs=True)
+        return sample.cpu(), probs.cpu()
+
+    tok_g, p_g = run(8)
+    tok_t, p_t = run(0)
+    m.check_errors()
+    with torch.no_grad():
+        p_ref = torch.softmax(oracle(tok_g, torch.zeros(B, dtype=torch.long)), dim=-1)[:, :n]      # (B, n, 30)
+    assert float((p_g.permute(1, 0, 2) - p_ref).abs().max()) < 5e-2
+    for b in range(B):
+        idx, mg = R.inverse_cdf(p_g[:, b], uni[:, b].cpu())
+        ok = mg > 1e-6
+        assert torch.equal(idx[ok], tok_g[b, 1:][ok])
+    # the two paths: same distributions within bf16 noise along a common prefix (they part at the first differing draw)
+    same = (tok_g == tok_t).all(dim=0).long().cumprod(0)
+    k = int(same.sum()) - 1                       # steps whose inputs are equal on both paths
+    assert k >= 1 and float((p_g[:k] - p_t[:k]).abs().max()) < 3e-2
+    tok_e, p_e = run(8, use_graph=False)
+    assert torch.equal(tok_e, tok_g) and torch.equal(p_e, p_g)
+    # more sequences than the streaming kernels take: the option changes nothing
+    u9 = torch.from_numpy(np.random.default_rng(99).random((n, 9), dtype=np.float32)).to(dev)
+    a, pa = run(8, rows=9, u=u9)
+    b_, pb = run(0, rows=9, u=u9)
+    assert torch.equal(a, b_) and torch.equal(pa, pb)
+
+
 def test_benchmark_configuration_pinned_to_the_oracle(dev):
     """BASELINE config 2 exactly as bench.py runs it - the real 56-layer OA_DM_640M(random_init=True) under seed 0 with
     bench.py's decoder sharpening, B = 64, L = 256, bf16, DEFAULT execution options (LayerNorms in the epilogues, pruned

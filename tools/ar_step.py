@@ -13,13 +13,13 @@ torch.manual_seed(0)
 m, _, tok, _ = LR_AR_640M(random_init=True)
 m.precision = "bf16"
 import os  # noqa: E402
-for opt, env in (("tile64_max", "ED_TILE64"), ("split_target", "ED_TARGET")):   # kernel-choice options, for A/B runs
+for opt, env in (("tile64_max", "ED_TILE64"), ("split_target", "ED_TARGET"), ("ar_gemv", "ED_AR_GEMV")):   # kernel-choice options, for A/B runs
     if env in os.environ:
         m.set_option(opt, int(os.environ[env]))
 dev = torch.device("cuda", 0)
 n = 256
 wbytes = 2.0 * sum(p.numel() for p in m.parameters())
-for B in (1, 8, 64, 256):
+for B in (1, 4, 8, 64, 256):
     uni = torch.rand((n, B), device=dev)
     best = 1e9
     for rep in range(3):
