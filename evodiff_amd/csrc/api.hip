@@ -121,9 +121,9 @@ struct ed_model {
   std::vector<DevBuf> Car;
   int ar_B = 0, ar_L = 0, ar_prec = -1;
   DevBuf ar_keep, ar_ndraw;   // ed_ar_sample_scaffold: given positions (L bytes), classes per step (n_steps ints)
-  int ar_gemv = 4;            // ED_OPT_AR_GEMV: autoregressive batches up to this many sequences take the weight-streaming
-                              // kernels (ar_gemv.hip); 0 = never, at most AR_GEMV_MAX_B.  Measured per step, 640M: 1.14 / 1.62 /
-                              // 2.25 ms at B = 1 / 4 / 8 against 1.99 / 2.01 / 2.04 on the tile kernels
+  int ar_gemv = 8;            // ED_OPT_AR_GEMV: autoregressive batches up to this many sequences take the weight-streaming
+                              // kernels (ar_gemv.hip); 0 = never, at most AR_GEMV_MAX_B.  Measured per step, 640M: 1.19 / 1.45 /
+                              // 1.71 ms at B = 1 / 4 / 8 against 1.99 / 2.01 / 2.04 on the tile kernels
   int n_cus = 0;              // compute units of the model's device
   bool ar_forced = false;     // the current autoregressive call uses them
   // LayerNorm fused into the tuned kernels' epilogues (ED_OPT_FUSE_LN, ln_epilogue.hpp): exchange buffer for the per-row

@@ -239,6 +239,7 @@ struct ArGemv {
   bf16_t* cache;         // ntaps > 1: [B][cache_pitch][C] bf16, position 0 at row cache_row0 (zero rows in front)
   long cache_pitch, cache_row0;
   PosBit pos;            // position of the new row
+  int ncol = 0;          // (set by the launcher: output columns of a workgroup and pass)
 };
 bool ar_gemv_supported(const ArGemv& p);
 hipError_t launch_ar_gemv(const ArGemv& p, int n_cus, hipStream_t stream);

@@ -202,10 +202,10 @@ int ed_model_check_errors(ed_model* m, void* stream, int synchronize);
  *     per-row partial statistics inside the launch - instead of a separate LayerNorm launch; the statistics are then
  *     taken on the fp32 sums rather than on their bf16 roundings.  0 = separate launches.  If a workgroup ever gives up
  *     waiting for its partners (bounded wait), the NEXT call on the model returns ED_EHIP.
- *   ED_OPT_AR_GEMV (default 4, range 0..8): ed_ar_sample / ed_ar_sample_scaffold with at most this many sequences (bf16,
+ *   ED_OPT_AR_GEMV (default 8, range 0..8): ed_ar_sample / ed_ar_sample_scaffold with at most this many sequences (bf16,
  *     kernel size 5) run every block as three weight-streaming launches, each applying the LayerNorm in front of its
- *     GEMM itself (no K loop cut across workgroups, no partial sums); 0 = always the tile kernels, as larger batches
- *     use.  The default is where the streaming kernels stop winning on the 640M model.
+ *     GEMM itself (no K loop cut across workgroups, no partial sums in memory); 0 = always the tile kernels, as larger
+ *     batches use.
  *   (Option 10, the round-2 block chain, was measured slower than one launch per GEMM and is gone; the number stays
  *   unused.) */
 enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1, ED_OPT_SPLIT_TARGET = 2, ED_OPT_INCREMENTAL = 3,

@@ -19,7 +19,7 @@ for opt, env in (("tile64_max", "ED_TILE64"), ("split_target", "ED_TARGET"), ("a
 dev = torch.device("cuda", 0)
 n = 256
 wbytes = 2.0 * sum(p.numel() for p in m.parameters())
-for B in (1, 4, 8, 64, 256):
+for B in [int(b) for b in os.environ.get("ED_AR_BATCHES", "1,4,8,64,256").split(",")]:
     uni = torch.rand((n, B), device=dev)
     best = 1e9
     for rep in range(3):
@@ -31,7 +31,7 @@ for B in (1, 4, 8, 64, 256):
         best = min(best, (time.perf_counter() - t0) / n)
     print(f"ed_ar_sample B={B:4d}: {best * 1e3:.3f} ms/step, {B / best:.0f} tokens/s, weights/time = "
           f"{wbytes / best / 1e12:.2f} TB/s", flush=True)
-for L in (64, 256, 1024):
+for L in (() if "ED_AR_BATCHES" in os.environ else (64, 256, 1024)):
     x = torch.randint(0, 26, (1, L), device=dev)
     t = torch.zeros(1, dtype=torch.long, device=dev)
     m(x, t)
