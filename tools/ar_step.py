@@ -9,10 +9,16 @@ import torch
 sys.path.insert(0, ".")
 from evodiff_amd.pretrained import LR_AR_640M  # noqa: E402
 
-torch.manual_seed(0)
-m, _, tok, _ = LR_AR_640M(random_init=True)
-m.precision = "bf16"
 import os  # noqa: E402
+
+torch.manual_seed(0)
+if "ED_AR_LAYERS" in os.environ:   # a 640M-wide causal model with fewer blocks: 8 blocks = 184 MB of bf16 weights, which
+    from evodiff_amd.model import ByteNetLMTime  # noqa: E402    stay in the 256 MB Infinity Cache between steps
+    m = ByteNetLMTime(30, 8, 1280, int(os.environ["ED_AR_LAYERS"]), 5, 128, causal=True, padding_idx=27, final_ln=True,
+                      slim=False, activation="gelu").eval()
+else:
+    m, _, tok, _ = LR_AR_640M(random_init=True)
+m.precision = "bf16"
 for opt, env in (("tile64_max", "ED_TILE64"), ("split_target", "ED_TARGET"), ("ar_gemv", "ED_AR_GEMV")):   # kernel-choice options, for A/B runs
     if env in os.environ:
         m.set_option(opt, int(os.environ[env]))
@@ -23,7 +29,7 @@ for B in [int(b) for b in os.environ.get("ED_AR_BATCHES", "1,4,8,64,256").split(
     uni = torch.rand((n, B), device=dev)
     best = 1e9
     for rep in range(3):
-        sample = torch.full((B, n + 1), tok.start_id, dtype=torch.long, device=dev)
+        sample = torch.full((B, n + 1), (29 if "ED_AR_LAYERS" in os.environ else tok.start_id), dtype=torch.long, device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         m.ar_sample(sample, uni, n_steps=n)
