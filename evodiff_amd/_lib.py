@@ -13,7 +13,7 @@ K_EMBED, K_LNACT, K_GEMM1X1, K_CONV, K_FINAL, K_CONV_OTHER, K_COUNT = 0, 1, 2, 3
 KIND_NAMES = ("embed", "ln_act", "gemm1x1", "conv", "final", "conv_other")
 OPTIONS = {"prune": 0, "min_tuned_tiles": 1, "split_target": 2, "incremental": 3, "fuse_reduce_ln": 4,
            "split_min_iters": 5, "partials_mb": 6, "tile64_max": 7,
-           "tuned_split_min_rows": 8, "fuse_ln": 9, "ar_gemv": 11}   # ED_OPT_* in include/evodiff_hip.h
+           "tuned_split_min_rows": 8, "fuse_ln": 9, "ar_gemv": 11, "ar_gemv_wgs": 12}   # ED_OPT_* in include/evodiff_hip.h
 
 # every symbol include/evodiff_hip.h declares
 SYMBOLS = ("ed_abi_version", "ed_last_error", "ed_model_create", "ed_model_destroy", "ed_model_load_tensor",

@@ -125,6 +125,7 @@ struct ed_model {
                               // kernels (ar_gemv.hip); 0 = never, at most AR_GEMV_MAX_B.  Measured per step, 640M: 1.19 / 1.45 /
                               // 1.71 ms at B = 1 / 4 / 8 against 1.99 / 2.01 / 2.04 on the tile kernels
   int n_cus = 0;              // compute units of the model's device
+  int ar_gemv_wgs = 0;        // ED_OPT_AR_GEMV_WGS: workgroups a weight-streaming launch uses at most (0 = one per CU)
   bool ar_forced = false;     // the current autoregressive call uses them
   // LayerNorm fused into the tuned kernels' epilogues (ED_OPT_FUSE_LN, ln_epilogue.hpp): exchange buffer for the per-row
   // partial statistics, arrival counters (one array per GEMM of the block: a counter must always see the same number of
@@ -752,7 +753,7 @@ int run_ar_step(ed_model* m, int B, int L, int n, int prec, float* probs, hipStr
   auto run_gemv = [&](const ArGemv& g, int kind) -> int {
     Probe pr(m, s);
     LAUNCH_TRY(pr.begin());
-    LAUNCH_TRY(launch_ar_gemv(g, m->n_cus, s));
+    LAUNCH_TRY(launch_ar_gemv(g, m->ar_gemv_wgs > 0 ? m->ar_gemv_wgs : m->n_cus, s));
     LAUNCH_TRY(pr.end(kind, 2.0 * g.B * g.N * (double)g.C * g.ntaps, (double)g.ntaps * g.N * g.C * 2.0));
     return ED_OK;
   };
@@ -1506,6 +1507,10 @@ int ed_model_set_option(ed_model* m, int option, int value) {
     case ED_OPT_AR_GEMV:
       if (value < 0 || value > AR_GEMV_MAX_B) return fail(ED_EINVAL, "ED_OPT_AR_GEMV must be in [0, 8]");
       m->ar_gemv = value;
+      break;
+    case ED_OPT_AR_GEMV_WGS:
+      if (value < 0 || value > 4096) return fail(ED_EINVAL, "ED_OPT_AR_GEMV_WGS must be in [0, 4096]");
+      m->ar_gemv_wgs = value;
       break;
     case ED_OPT_SPLIT_MIN_ITERS:
       if (value < 1 || value > 64) return fail(ED_EINVAL, "ED_OPT_SPLIT_MIN_ITERS must be in [1, 64]");

@@ -206,11 +206,15 @@ int ed_model_check_errors(ed_model* m, void* stream, int synchronize);
  *     kernel size 5) run every block as three weight-streaming launches, each applying the LayerNorm in front of its
  *     GEMM itself (no K loop cut across workgroups, no partial sums in memory); 0 = always the tile kernels, as larger
  *     batches use.
+ *   ED_OPT_AR_GEMV_WGS (default 0 = one per compute unit): the most workgroups a weight-streaming launch uses; with fewer
+ *     than its column groups a workgroup works through several groups in passes (the tests use it to reach that path,
+ *     which the widths the kernels accept never reach on 256 CUs).
  *   (Option 10, the round-2 block chain, was measured slower than one launch per GEMM and is gone; the number stays
  *   unused.) */
 enum { ED_OPT_PRUNE = 0, ED_OPT_MIN_TUNED_TILES = 1, ED_OPT_SPLIT_TARGET = 2, ED_OPT_INCREMENTAL = 3,
        ED_OPT_FUSE_REDUCE_LN = 4, ED_OPT_SPLIT_MIN_ITERS = 5, ED_OPT_PARTIALS_MB = 6, ED_OPT_TILE64_MAX = 7,
-       ED_OPT_TUNED_SPLIT_MIN_ROWS = 8, ED_OPT_FUSE_LN = 9, ED_OPT_AR_GEMV = 11 };
+       ED_OPT_TUNED_SPLIT_MIN_ROWS = 8, ED_OPT_FUSE_LN = 9, ED_OPT_AR_GEMV = 11,
+       ED_OPT_AR_GEMV_WGS = 12 };
 int ed_model_set_option(ed_model* m, int option, int value);
 
 /* Measurement hooks (no counterpart in the reference).  With a probe interval n > 0, every n-th

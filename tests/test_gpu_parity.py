@@ -1020,6 +1020,12 @@ def test_autoregressive_weight_streaming_kernels_against_oracle_and_tile_kernels
     assert k >= 1 and float((p_g[:k] - p_t[:k]).abs().max()) < 3e-2
     tok_e, p_e = run(8, use_graph=False)
     assert torch.equal(tok_e, tok_g) and torch.equal(p_e, p_g)
+    # few workgroups: every workgroup (wave, for one sequence) works through several column groups in passes - the same
+    # sums in the same order, so bit-equal
+    m.set_option("ar_gemv_wgs", 3)
+    tok_w, p_w = run(8)
+    m.set_option("ar_gemv_wgs", 0)
+    assert torch.equal(tok_w, tok_g) and torch.equal(p_w, p_g)
     # more sequences than the streaming kernels take: the option changes nothing
     u9 = torch.from_numpy(np.random.default_rng(99).random((n, 9), dtype=np.float32)).to(dev)
     a, pa = run(8, rows=9, u=u9)
