@@ -141,7 +141,7 @@ def measured_traffic(args):
     configuration is not the one the counters were collected on)."""
     if not (args.model == "640M" and args.batch == 64 and args.seq_len == 256 and args.precision == "bf16"):
         return None
-    for name in ("r02_conv_window_traffic.json", "r01_conv_window_traffic.json"):
+    for name in ("r03_conv_window_traffic.json", "r02_conv_window_traffic.json", "r01_conv_window_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"]

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from evodiff_amd.pretrained import LR_AR_640M  # noqa: E402
 
 import os  # noqa: E402
