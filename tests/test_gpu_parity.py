@@ -1033,6 +1033,101 @@ def test_autoregressive_weight_streaming_kernels_against_oracle_and_tile_kernels
     assert torch.equal(a, b_) and torch.equal(pa, pb)
 
 
+def random_geometry_case(seed, dev):
+    """One case of the random-geometry sweep (tools/fuzz_parity.py runs many; six are in the suite below): forward in
+    fp32 and bf16 against the oracle; non-causal without timesteps, a free-running fp32 OA-DM loop with default options
+    checked draw by draw against the oracle teacher-forced along the GPU's trajectory and bit-equal to the loop with
+    pruning / incremental layers / graph replay off; causal, a cached bf16 autoregressive loop checked per step against
+    the oracle's causal forward of the sampled sequences.  Returns a one-line summary; asserts on any difference."""
+    rng = np.random.default_rng(seed)
+    d_model = int(rng.choice([64, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280]))
+    cfg = dict(d_embed=8, d_model=d_model, n_layers=int(rng.integers(1, 11 if d_model <= 640 else 6)), kernel_size=5,
+               r=int(rng.choice([1, 4, 16, 128])), slim=bool(rng.integers(0, 2)), activation=str(rng.choice(["gelu", "relu"])))
+    causal = bool(rng.integers(0, 3) == 0)
+    timesteps = None if causal or rng.integers(0, 2) else 500
+    B = int(rng.integers(1, 13))
+    L = int(rng.choice([1, 2, 5, 31, 64, 100, 127, 128, 129, 255, 256, 257, 300, 511, 600])) if d_model <= 640 else \
+        int(rng.choice([3, 64, 130, 256]))
+    if causal:
+        cfg.update(causal=True, n_tokens=30)
+    tag = f"seed {seed}: {cfg} timesteps={timesteps} B={B} L={L}"
+    oracle = R.build_model(cfg, timesteps, 100 + seed)
+    with torch.no_grad():
+        oracle.decoder.conv.weight.mul_(4.0)
+    m = product_model(oracle, cfg, timesteps=timesteps)
+    n_tok = cfg.get("n_tokens", 31)
+    x = torch.from_numpy(rng.integers(0, n_tok, (B, L)))
+    y = torch.from_numpy(rng.integers(0, timesteps, (B,))) if timesteps else torch.zeros(B, dtype=torch.long)
+    with torch.no_grad():
+        ref = oracle(x, y).numpy()
+    e32 = rel_err(m(x.to(dev), y.to(dev)).cpu().numpy(), ref)
+    m.precision = "bf16"
+    e16 = rel_err(m(x.to(dev), y.to(dev)).cpu().numpy(), ref)
+    assert e32 < FP32_TOL and e16 < BF16_TOL, f"{tag}: forward fp32 {e32:.2e} bf16 {e16:.2e}"
+    extra = ""
+    if not causal and timesteps is None and L >= 2:
+        m.precision = "fp32"
+        n = min(L, 24)
+        order = torch.from_numpy(rng.permutation(L)[:n].astype(np.int32))
+        uni = torch.from_numpy(rng.random((n, B), dtype=np.float32))
+
+        def run(**opts):
+            for k, v in opts.items():
+                if k == "graph":
+                    m.use_graph = bool(v)
+                else:
+                    m.set_option(k, v)
+            s = torch.full((B, L), R.MASK_ID, dtype=torch.long, device=dev)
+            p = m.oadm_sample(s, order.to(dev), uni.to(dev), R.OADM_DRAW, return_probs=True)
+            return s.cpu(), p.cpu()
+
+        s0, p0 = run(prune=1, incremental=1, graph=1)
+        s1, p1 = run(prune=0, incremental=0, graph=0)
+        assert torch.equal(s0, s1) and torch.equal(p0, p1), f"{tag}: options change the fp32 loop"
+        m.set_option("prune", 1)
+        m.set_option("incremental", 1)
+        m.use_graph = True
+        safe = 0
+        for s in range(n):
+            state = s0.clone()
+            state[:, order[s:].long()] = R.MASK_ID
+            with torch.no_grad():
+                lg = oracle(state, torch.zeros(B, dtype=torch.long))[:, int(order[s]), :R.OADM_DRAW]
+            pr = torch.softmax(lg, dim=-1)
+            assert float((pr - p0[s]).abs().max()) < 1e-4, f"{tag}: step {s} probabilities"
+            idx, margin = R.inverse_cdf(pr, uni[s])
+            ok = margin > DRAW_MARGIN_FP32
+            assert torch.equal(idx[ok], s0[:, int(order[s])][ok]), f"{tag}: step {s} draws"
+            safe += int(ok.sum())
+        extra = f", OA-DM {n} steps ok ({safe} draws compared)"
+    if causal and L >= 2:
+        m.precision = "bf16"
+        n = min(L - 1, 40)
+        uni = torch.from_numpy(rng.random((n, B), dtype=np.float32))
+        s = torch.full((B, n + 1), 29, dtype=torch.long, device=dev)
+        p = m.ar_sample(s, uni.to(dev), n_steps=n, return_probs=True).cpu()
+        s = s.cpu()
+        with torch.no_grad():
+            pr = torch.softmax(oracle(s, torch.zeros(B, dtype=torch.long)), dim=-1)[:, :n]
+        d = float((p.permute(1, 0, 2) - pr).abs().max())
+        assert d < 5e-2, f"{tag}: autoregressive probabilities differ by {d:.3f}"
+        for b in range(B):
+            idx, mg = R.inverse_cdf(p[:, b], uni[:, b])
+            ok = mg > 1e-6
+            assert torch.equal(idx[ok], s[b, 1:][ok]), f"{tag}: autoregressive draws"
+        extra = f", AR {n} steps ok (max |dp| {d:.1e})"
+    m.check_errors()
+    return f"{tag}: fp32 {e32:.1e} bf16 {e16:.1e}{extra}"
+
+
+@pytest.mark.parametrize("seed", [1, 5, 6, 9, 16, 27])
+def test_random_geometries_from_the_parity_sweep(dev, seed):
+    """Six cases of the sweep (430 random geometries, all green: profiles/r03_fuzz_parity.txt) kept as regression:
+    dilation schedules r = 1 / 4 / 16, ReLU blocks, widths 320 / 384 (no tuned kernel), slim and full hidden layers,
+    L = 600 / 255 / 127, causal models with the cached autoregressive loop on the weight-streaming kernels."""
+    random_geometry_case(seed, dev)
+
+
 def test_benchmark_configuration_pinned_to_the_oracle(dev):
     """BASELINE config 2 exactly as bench.py runs it - the real 56-layer OA_DM_640M(random_init=True) under seed 0 with
     bench.py's decoder sharpening, B = 64, L = 256, bf16, DEFAULT execution options (LayerNorms in the epilogues, pruned
